@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.json from the REFERENCE, in the build container only.
+
+Two kinds of fixture are written:
+
+* ``known_answers.json`` -- the known-answer vectors the reference's own tests hold for this
+  path, restated as data (input / configuration / expected bytes) with the file:line they come
+  from.  Each one is re-checked here against the reference C library before it is written.
+* ``generated.json`` -- outputs of the reference C library itself (oracle/_ref/libtamp_ref.so,
+  built in place from /root/reference by oracle/Makefile) on this repo's deterministic synthetic
+  inputs (tamp_amd/workloads.py), one record per (workload, stream, configuration): SHA-256 of
+  the input, the compressed bytes (base64) and the decode status/size.
+* ``dictionaries.json`` -- tamp_initialize_dictionary for every (size, literal) pair.
+* ``device_vectors.json`` -- the reference's malformed/valid decoder vectors
+  (devices/vectors/*.bin, data files its own tests replay) with the status/output the reference
+  decoder produces for them.
+
+Nothing under /root/reference is copied except those small data vectors; `/root/reference`
+does not exist on the GPU box and no test reads it at run time.
+"""
+import base64
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.checker import Ref  # noqa: E402
+from tamp_amd import workloads as wl  # noqa: E402
+
+REFROOT = "/root/reference"
+
+
+def b64(b: bytes) -> str:
+    return base64.b64encode(b).decode()
+
+
+def sha(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()
+
+
+def dict_with(size: int, fill: int, patches) -> bytes:
+    d = bytearray([fill]) * size
+    for off, data in patches:
+        d[off : off + len(data)] = data
+    return bytes(d)
+
+
+def known_answers(ref: Ref):
+    foo = b"foo foo foo"
+    foo_v1 = bytes.fromhex("58b3041c8100030000")
+    comp = [
+        # name, cite, conf, dictionary, input, expected
+        ("foo_v1", "tests/test_compressor.py:66-105", dict(window=10, literal=8, extended=False), None, foo, foo_v1),
+        ("foo_7bit", "tests/test_compressor.py:145-170", dict(window=10, literal=7, extended=False), None, foo,
+         bytes([0b01010000, 0b11100110, 0b00001000, 0b00111010, 0b00000100, 0b00000000, 0b00001100, 0b00000000])),
+        ("foo_predefined_dictionary", "tests/test_compressor.py:172-198", dict(window=8, literal=7, extended=False),
+         dict_with(256, 0, [(0, foo)]), foo, bytes([0b00010100, 0b01010100, 0b00000000])),
+        ("oob_2_byte_pattern", "tests/test_compressor.py:207-236", dict(window=10, literal=8, extended=False), None,
+         b"Q\x00Q", bytes([0b01011000, 0b10101000, 0b11000000, 0b00101010, 0b00100000])),
+        ("extended_rle_20", "tests/test_compressor.py:307-332", dict(window=10, literal=8, extended=True), None,
+         b"A" * 20, bytes([0x5A, 0xA0, 0xAA, 0xB1])),
+        ("extended_rle_5", "tests/test_compressor.py:334-356", dict(window=10, literal=8, extended=True), None,
+         b"B" * 5, bytes([0x5A, 0xA1, 0x2A, 0x84])),
+        ("extended_match_14", "tests/test_compressor.py:358-391", dict(window=8, literal=8, extended=True),
+         dict_with(256, 0, [(0, b"abcdefghijklmn")]), b"abcdefghijklmn", bytes([0x1E, 0x4E, 0x00, 0x00])),
+        ("extended_match_16", "tests/test_compressor.py:393-418", dict(window=8, literal=8, extended=True),
+         dict_with(256, 0, [(0, b"abcdefghijklmnop")]), b"abcdefghijklmnop", bytes([0x1E, 0x4E, 0x40, 0x00])),
+        ("finder_window_edge", "ctests/test_compressor.c:802-810", dict(window=8, literal=8, extended=False),
+         dict_with(256, ord("a"), [(250, b"UVWXYZ")]), b"WXYZ!!", bytes([0x1C, 0x47, 0xE4, 0x86, 0x42])),
+        ("finder_alignment_phases", "ctests/test_compressor.c:812-824", dict(window=8, literal=8, extended=False),
+         dict_with(256, 0xFF, [(3, b"Qa"), (13, b"Qab"), (26, b"Qabc"), (40, b"Qabcd")]), b"Qabcd",
+         bytes([0x1C, 0x59, 0x40])),
+        ("finder_swar_bytes", "ctests/test_compressor.c:826-838", dict(window=8, literal=8, extended=False),
+         dict_with(256, 0x01, [(10, b"\x00\x7f"), (50, b"\x80\x00\x80"), (100, b"\x00\x00\x00"),
+                               (200, b"\x00\x80\x7f\x01\xff")]), b"\x00\x80\x7f\x01\xff", bytes([0x1C, 0x5E, 0x40])),
+        ("finder_max_pattern_early_exit", "ctests/test_compressor.c:840-848",
+         dict(window=8, literal=8, extended=False), dict_with(256, ord("z"), [(30, b"ABCDEFGHIJKLMNOP")]),
+         b"ABCDEFGHIJKLMNOP", bytes([0x1C, 0x4E, 0x3D, 0x50])),
+        ("default_is_extended", "BASELINE.md section 1 (measured from the reference C)",
+         dict(window=10, literal=8, extended=True), None, foo, bytes.fromhex("5ab3041c8100030000")),
+    ]
+    payload = b"payload " * 20
+    big = ref.initialize_dictionary(4096)
+    decomp = [
+        # name, cite, compressed, dictionary, expected output, expected status
+        ("foo_v1", "tests/test_decompressor.py:40-67", foo_v1, None, foo, 2),
+        ("flush_tokens", "tests/test_decompressor.py:96-113",
+         bytes([0b01011000, 0b10101000, 0b10101010, 0b11000000, 0b10101011, 0b10101010, 0b11000000]), None, b"QW", 2),
+        ("dst_immediately_after_src", "tests/test_decompressor.py:124-158",
+         bytes([0b01011100, 0b10110000, 0b10110000, 0b00000000]), dict_with(1024, 0, [(0, b"abcd")]), b"aabc", 2),
+        ("extended_rle_20", "tests/test_decompressor.py:193-211", bytes([0x5A, 0xA0, 0xAA, 0xB1]), None, b"A" * 20, 2),
+        ("extended_rle_5", "tests/test_decompressor.py:213-230", bytes([0x5A, 0xA1, 0x2A, 0x84]), None, b"B" * 5, 2),
+        ("extended_match_14", "tests/test_decompressor.py:232-254", bytes([0x1E, 0x4E, 0x00, 0x00]),
+         dict_with(256, 0, [(0, b"abcdefghijklmn")]), b"abcdefghijklmn", 2),
+        ("malicious_oob", "ctests/test_decompressor.c:74-98", bytes([0b01011000, 0b00111111, 0b11110000]), None, b"",
+         -4),
+        ("oversized_custom_dictionary", "tests/test_bug_regressions.py:177-190",
+         bytes.fromhex("5eb8586f36c06cb248130009c8004f08004f320013c20000"), big, payload, 2),
+        ("default_stream", "tests/test_bug_regressions.py:179,210-220",
+         bytes.fromhex("5ab8586f36c06cb248130009c8004f08004f320013c20000"), None, payload, 2),
+    ]
+    out = {"compress": [], "decompress": []}
+    for name, cite, conf, d, data, expected in comp:
+        st, got = ref.compress(data, dictionary=d, **conf)
+        assert st == 0 and got == expected, (name, st, got.hex(), expected.hex())
+        out["compress"].append(dict(name=name, cite=cite, conf=conf, dictionary=b64(d) if d else None,
+                                    input=b64(data), expected=expected.hex()))
+    for name, cite, comp_bytes, d, expected, status in decomp:
+        st, got, _ = ref.decompress(comp_bytes, dictionary=d, cap=4096)
+        assert st == status and got == expected, (name, st, got, expected)
+        out["decompress"].append(dict(name=name, cite=cite, compressed=comp_bytes.hex(),
+                                      dictionary=b64(d) if d else None, expected=b64(expected), status=status))
+    return out
+
+
+def dictionaries(ref: Ref):
+    expected_256 = (
+        b"\x00.//r.0. t>\n/>snas.trnr i\x00r/a\x00snat./.r\x00i o.s tneo>.as>\na.ta\x00 aa\x00\x00\x000oe ri\x00a>eatsi\n.\ni.str\n"
+        b"//snesr.ost<  \x00\ni\neoa\x00se0.o\n\n>aori>n0.>./.oonen0<\x00<r o\n\naas0< ai\n0\x00na\x00e><.\noas to \n></se>>ts/"
+        b"oreatinter.n0 >s\n/.e.><. r si<>/<san\x00ae t 0.r.o/0./a r/ttn nn.<re.t0 \x00r\x00ro"
+    )  # tests/test_pseudorandom.py:22-24
+    assert ref.initialize_dictionary(256, 8) == expected_256
+    recs = []
+    for wbits in range(8, 16):
+        for lit in (5, 6, 7, 8):
+            d = ref.initialize_dictionary(1 << wbits, lit)
+            recs.append(dict(size=1 << wbits, literal=lit, sha256=sha(d), head=d[:32].hex()))
+    return dict(cite="tests/test_pseudorandom.py:22-24; common.c:18-52", first256_literal8=expected_256.hex(),
+                table=recs)
+
+
+def generated(ref: Ref):
+    cases = []
+
+    def add(workload, rows, confs, dictionary=None, dict_name=None):
+        for i, row in enumerate(rows):
+            data = row.tobytes()
+            for conf in confs:
+                st, comp = ref.compress(data, dictionary=dictionary, **conf)
+                dst, dout, _ = ref.decompress(comp, dictionary=dictionary, cap=len(data) + 64) if st == 0 else (None, b"", 0)
+                if st == 0:
+                    assert dst == 2 and dout == data
+                cases.append(dict(workload=workload, index=i, length=len(data), input_sha256=sha(data), conf=conf,
+                                  dictionary=dict_name, status=st, compressed=b64(comp), compressed_sha256=sha(comp)))
+
+    base = [dict(window=10, literal=8, extended=False), dict(window=10, literal=8, extended=True)]
+    add("synth_text:4096", wl.synth_text(24, 4096), base)
+    add("synth_text:4096", wl.synth_text(4, 4096), [dict(window=w, literal=8, extended=True) for w in (8, 9, 11, 12)] +
+        [dict(window=12, literal=8, extended=False), dict(window=15, literal=8, extended=True),
+         dict(window=10, literal=8, extended=True, lazy_matching=True),
+         dict(window=10, literal=8, extended=False, lazy_matching=True)])
+    add("synth_text:65536", wl.synth_text(1, 65536), base)
+    add("synth_text:777", wl.synth_text(6, 777), base)
+    add("lcg_runs:512", wl.lcg_runs(24, 512), base + [dict(window=8, literal=8, extended=True)])
+    add("stress:8192", wl.stress(6, 8192), [dict(window=w, literal=8, extended=e) for w in (8, 10, 12) for e in (False, True)])
+    for n in (0, 1, 2, 3, 15, 16, 17, 31, 32, 33):
+        add(f"synth_text:{n}", wl.synth_text(2, n), base)
+    tel_dict = wl.telemetry_dictionary(ref.initialize_dictionary(256, 7))
+    add("telemetry:256", wl.telemetry(24, 256), [dict(window=8, literal=7, extended=True)], tel_dict, "telemetry")
+    add("telemetry:256", wl.telemetry(8, 256), [dict(window=8, literal=7, extended=False),
+                                                dict(window=8, literal=7, extended=True)])
+    # EXCESS_BITS: a byte >= 0x80 under literal=7
+    bad = wl.telemetry(4, 256).copy()
+    bad[1, 40] = 0xC3
+    bad[2, 0] = 0x80
+    bad[3, 255] = 0xFF
+    add("telemetry_bad:256", bad, [dict(window=8, literal=7, extended=True)], tel_dict, "telemetry")
+    # 5/6-bit literals on masked text (dictionary tables for small literals; min_pattern 3 at w>=11..)
+    txt = wl.synth_text(3, 1500)
+    add("synth_text&31:1500", txt & 31, [dict(window=w, literal=5, extended=e) for w in (8, 10, 11, 13) for e in (False, True)])
+    add("synth_text&63:1500", txt & 63, [dict(window=w, literal=6, extended=True) for w in (10, 12, 13)])
+    return dict(note="outputs of oracle/_ref/libtamp_ref.so (reference C, -O3, TAMP_LAZY_MATCHING=1)",
+                telemetry_dictionary=b64(tel_dict), cases=cases)
+
+
+def device_vectors(ref: Ref):
+    recs = []
+    vdir = os.path.join(REFROOT, "devices", "vectors")
+    for name in sorted(os.listdir(vdir)):
+        data = open(os.path.join(vdir, name), "rb").read()
+        st, out, consumed = ref.decompress(data, cap=1 << 16)
+        recs.append(dict(name=name, cite=f"devices/vectors/{name} (replayed by devices/common/tamp_bench.c:228-273)",
+                         data=b64(data), status=st, output=b64(out), consumed=consumed))
+    return recs
+
+
+def main():
+    ref = Ref()
+    assert ref.sizes() == (2, 48, 24), ref.sizes()
+    for fname, obj in (
+        ("known_answers.json", known_answers(ref)),
+        ("dictionaries.json", dictionaries(ref)),
+        ("generated.json", generated(ref)),
+        ("device_vectors.json", device_vectors(ref)),
+    ):
+        with open(os.path.join(HERE, fname), "w") as f:
+            json.dump(obj, f, indent=0, sort_keys=True)
+        print(fname, os.path.getsize(os.path.join(HERE, fname)))
+
+
+if __name__ == "__main__":
+    main()
