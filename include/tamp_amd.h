@@ -1,0 +1,163 @@
+/*
+ * tamp_amd.h -- C ABI of libtamp_amd.so: the MI355X-native batch codec for the Tamp `.tamp` format.
+ *
+ * This is the drop-in boundary for the reference's hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).  Plain pointers and
+ * sizes only; no torch / C++ types cross this boundary.  Every codec call runs hand-written HIP
+ * kernels on a gfx950 device: there is no CPU fallback -- without a device the calls return
+ * TAMP_AMD_NO_DEVICE (-20) and compute nothing.
+ *
+ * Status codes are the reference's tamp_res values (tamp/_c_src/tamp/common.h:145-168).
+ */
+#ifndef TAMP_AMD_H
+#define TAMP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: identical numbering to tamp_res (common.h:145-168) ---- */
+enum {
+    TAMP_OK = 0,
+    TAMP_OUTPUT_FULL = 1,
+    TAMP_INPUT_EXHAUSTED = 2,
+    TAMP_ERROR = -1,
+    TAMP_EXCESS_BITS = -2,
+    TAMP_INVALID_CONF = -3,
+    TAMP_OOB = -4,
+    /* library-level failures of this implementation (outside the reference's range) */
+    TAMP_AMD_NO_DEVICE = -20, /* no HIP device / HIP runtime error: nothing was computed */
+    TAMP_AMD_BAD_ARGUMENT = -21,
+};
+typedef int8_t tamp_res;
+
+/* Unpacked twin of TampConf (common.h:170-182).  One configuration per batch launch. */
+typedef struct TampAmdConf {
+    uint8_t window;                /* 8..15 */
+    uint8_t literal;               /* 5..8  */
+    uint8_t use_custom_dictionary; /* `dictionary` argument holds 1<<window bytes shared by all streams */
+    uint8_t extended;              /* library default of the reference is 1 (compressor.c:193-203) */
+    uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
+    uint8_t lazy_matching;         /* must be 0 in this release */
+    uint8_t reserved[2];
+} TampAmdConf;
+
+/* Where the data pointers of a batch call live. */
+enum {
+    TAMP_AMD_MEM_HOST = 0,   /* host pointers: the library stages H2D / D2H itself */
+    TAMP_AMD_MEM_DEVICE = 1, /* device pointers on `device`: zero-copy, kernels only */
+};
+
+/* ---- host helpers (no device needed) -------------------------------------------------------- */
+
+/* Replaces tamp_initialize_dictionary (common.h:395, common.c:37-52). */
+void tamp_initialize_dictionary(unsigned char *buffer, size_t size, uint8_t literal);
+
+/* Replaces tamp_compute_min_pattern_size (common.h:405, common.c:54-56). */
+int8_t tamp_compute_min_pattern_size(uint8_t window, uint8_t literal);
+
+/* Worst-case compressed size of an n-byte stream: header byte(s) + every byte a literal
+ * (compressor.h flush table / SURVEY.md H7). */
+size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset);
+
+/* Number of visible HIP devices (0 when there is none), and the library version string. */
+int tamp_amd_device_count(void);
+const char *tamp_amd_version(void);
+
+/* Text of the last HIP runtime failure seen by the calling thread ("" if none): what TAMP_AMD_NO_DEVICE meant. */
+const char *tamp_amd_last_error(void);
+
+/* ---- batch codec ---------------------------------------------------------------------------- */
+
+/*
+ * Compress n_streams independent streams.  Stream i's bytes are identical to what
+ *     tamp_compressor_init(&c, &conf, window)                             (compressor.h:84)
+ *     tamp_compressor_compress_and_flush(&c, out, cap, &w, in, n, &consumed, false)
+ *                                                                         (compressor.h:280-286)
+ * produce in the reference on a freshly initialised compressor -- the call every reference
+ * benchmark times (tools/c-profiler/main.c:52-54, devices/common/tamp_bench.c:118-121) and that
+ * tamp.compress() performs (tamp/_c_compressor.pyx:189-199).
+ *
+ *   in[in_off[i] .. in_off[i]+in_len[i])        input bytes of stream i
+ *   out[out_off[i] .. out_off[i]+out_cap[i])    output slab of stream i
+ *   out_len[i]                                  bytes produced
+ *   status[i]                                   TAMP_OK, TAMP_OUTPUT_FULL (slab too small; out_len[i] <= out_cap[i]
+ *                                               bytes of valid prefix), TAMP_EXCESS_BITS (a literal does not fit
+ *                                               conf->literal bits, compressor.c:629-631; out_len[i] = whole bytes
+ *                                               emitted before it), or TAMP_INVALID_CONF
+ *   dictionary                                  1<<window bytes shared by every stream when
+ *                                               conf->use_custom_dictionary, else NULL (each stream starts from
+ *                                               its own pristine copy)
+ *   max_in_len                                  upper bound on in_len[] (sizes the per-workgroup LDS block); 0 = unknown:
+ *                                               computed from in_len for host memory, 4096-position blocks for
+ *                                               device memory (any length still works, in several epochs)
+ *   mem                                         TAMP_AMD_MEM_HOST or TAMP_AMD_MEM_DEVICE: applies to ALL pointer
+ *                                               arguments except conf
+ *   device                                      HIP device ordinal
+ *   stream                                      hipStream_t (as void*) to enqueue on, or NULL for the default
+ *                                               stream.  With device memory the call is asynchronous on `stream`;
+ *                                               with host memory it synchronises before returning.
+ * Returns TAMP_OK when the batch was launched (per-stream results are in status[]), or a negative
+ * library-level code.
+ */
+int tamp_batch_compress(const TampAmdConf *conf, const uint8_t *dictionary, const uint8_t *in, const uint64_t *in_off,
+                        const uint32_t *in_len, uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap,
+                        uint32_t *out_len, int8_t *status, size_t n_streams, uint32_t max_in_len, int mem, int device,
+                        void *stream);
+
+/*
+ * Decompress n_streams independent `.tamp` streams.  Stream i's bytes and status are identical to
+ *     tamp_decompressor_init(&d, NULL, window, max_window_bits)           (decompressor.h:83)
+ *     tamp_decompressor_decompress(&d, out, cap, &w, in, n, &consumed)    (decompressor.h:128)
+ * i.e. the configuration is read from each stream's own header (window 8..15 may differ per stream),
+ * normal completion is TAMP_INPUT_EXHAUSTED (2) (decompressor.h:125-126), a full output slab with
+ * work left is TAMP_OUTPUT_FULL (1), and malformed input yields TAMP_OOB / TAMP_INVALID_CONF
+ * (decompressor.c:232-236,284,311,540-544) -- never a crash.
+ *
+ *   dictionary / dictionary_len   custom dictionary for streams whose header has the custom bit
+ *                                 (>= 1<<window bytes, prefix used; such a stream with dictionary == NULL gets
+ *                                 TAMP_INVALID_CONF, where the Python surface raises ValueError,
+ *                                 tamp/_c_decompressor.pyx:63-64)
+ *   max_window_bits               streams whose header asks for more get TAMP_INVALID_CONF (decompressor.c:311)
+ *   in_consumed                   optional (may be NULL): compressed bytes consumed per stream
+ */
+int tamp_batch_decompress(const uint8_t *dictionary, size_t dictionary_len, uint8_t max_window_bits, const uint8_t *in,
+                          const uint64_t *in_off, const uint32_t *in_len, uint8_t *out, const uint64_t *out_off,
+                          const uint32_t *out_cap, uint32_t *out_len, int8_t *status, uint32_t *in_consumed,
+                          size_t n_streams, int mem, int device, void *stream);
+
+/* ---- single-stream one-shot entry points (the reference's own call shapes) ------------------- */
+
+/*
+ * One stream, host buffers: tamp_compressor_init + tamp_compressor_compress_and_flush(write_token=false)
+ * (compressor.h:84,280-286) as a batch of one on `device`.  *output_written_size may be NULL.
+ */
+tamp_res tamp_amd_compress(const TampAmdConf *conf, const unsigned char *dictionary, unsigned char *output,
+                           size_t output_size, size_t *output_written_size, const unsigned char *input,
+                           size_t input_size, int device);
+
+/*
+ * One stream, host buffers: tamp_decompressor_init(conf=NULL) + tamp_decompressor_decompress
+ * (decompressor.h:83,128) as a batch of one on `device`.
+ */
+tamp_res tamp_amd_decompress(const unsigned char *dictionary, size_t dictionary_len, unsigned char *output,
+                             size_t output_size, size_t *output_written_size, const unsigned char *input,
+                             size_t input_size, size_t *input_consumed_size, int device);
+
+/* Replaces tamp_decompressor_read_header (decompressor.h:67, decompressor.c:276-297): host-side header parse. */
+tamp_res tamp_amd_read_header(TampAmdConf *conf, const unsigned char *input, size_t input_size,
+                              size_t *input_consumed_size);
+
+/* Timing hook for bench.py: duration in milliseconds of the most recent codec kernel launched by this
+ * thread on `device`, measured with hipEvents on the stream the kernel ran on; < 0 if none recorded.
+ * Enabled by tamp_amd_set_timing(1). */
+void tamp_amd_set_timing(int enabled);
+float tamp_amd_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMP_AMD_H */

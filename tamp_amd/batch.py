@@ -1,0 +1,216 @@
+"""Batch entry points: many independent streams per launch (the hot path of this package).
+
+``compress_batch`` / ``decompress_batch`` take either host data (bytes-likes / numpy) or data already
+resident in HBM (torch CUDA tensors); torch is used only as a device-memory container -- pointers go
+straight into the C ABI (include/tamp_amd.h).  CSR contract: stream ``i`` is
+``data[in_off[i] : in_off[i] + in_len[i]]``; results land in ``out[out_off[i] : out_off[i] + out_len[i]]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import TampAmdConf
+
+
+def compress_bound(n: int, literal: int = 8, dictionary_reset: bool = False) -> int:
+    """Worst-case ``.tamp`` size of an ``n``-byte stream (every byte a literal)."""
+    return 1 + int(bool(dictionary_reset)) + (n * (literal + 1) + 7) // 8
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+@dataclass
+class BatchResult:
+    out: object          # uint8 buffer (numpy array or torch tensor) holding every stream's slab
+    out_off: object      # uint64/int64 [n]
+    out_len: object      # uint32/int32 [n]
+    status: object       # int8 [n] -- tamp_res per stream
+    in_consumed: object = None
+    kernel_ms: float = -1.0
+
+    def stream(self, i: int) -> bytes:
+        o, n = int(self.out_off[i]), int(self.out_len[i])
+        chunk = self.out[o : o + n]
+        return bytes(chunk.cpu().numpy()) if _is_torch(chunk) else chunk.tobytes()
+
+    def streams(self):
+        return [self.stream(i) for i in range(len(self.out_len))]
+
+
+def _conf(window, literal, extended, dictionary, dictionary_reset=False, lazy_matching=False) -> TampAmdConf:
+    return TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), int(bool(dictionary_reset)),
+                       int(bool(lazy_matching)))
+
+
+def _np_u8(x) -> np.ndarray:
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x.reshape(-1), dtype=np.uint8)
+    return np.frombuffer(bytes(x), dtype=np.uint8)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_streams(streams: Sequence[bytes]):
+    """list of bytes -> (flat uint8 array, in_off uint64[n], in_len uint32[n])."""
+    lens = np.fromiter((len(s) for s in streams), dtype=np.uint32, count=len(streams))
+    offs = np.zeros(len(streams), dtype=np.uint64)
+    if len(streams):
+        offs[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    flat = np.frombuffer(b"".join(bytes(s) for s in streams), dtype=np.uint8) if len(streams) else np.zeros(0, np.uint8)
+    return flat, offs, lens
+
+
+def _slab_offsets(caps: np.ndarray):
+    offs = np.zeros(len(caps), dtype=np.uint64)
+    if len(caps):
+        offs[1:] = np.cumsum(caps.astype(np.uint64))[:-1]
+    return offs, int(caps.astype(np.uint64).sum())
+
+
+def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
+                   dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
+                   max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False) -> BatchResult:
+    """Compress many independent streams in one launch.
+
+    ``data`` is a list of bytes-likes (host), a flat numpy uint8 array + ``in_off``/``in_len`` (host), or a flat
+    torch CUDA uint8 tensor + CUDA ``in_off`` (int64) / ``in_len`` (int32) tensors (device, zero-copy).
+    Stream ``i``'s output equals ``tamp.compress(stream_i, window=..., literal=..., dictionary=..., extended=...)``
+    of the reference.  ``status[i]`` holds the reference's ``tamp_res`` code for that stream.
+    """
+    lib = _lib.load()
+    conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching)
+    if dictionary is not None and not _is_torch(dictionary) and len(dictionary) != (1 << window):
+        raise ValueError("Dictionary-window size mismatch.")  # tamp/_c_compressor.pyx:43-46
+    lib.tamp_amd_set_timing(1 if timing else 0)
+
+    if _is_torch(data):
+        import torch
+
+        n = int(in_len.numel())
+        dev = data.device
+        if out_cap is None:
+            if not max_in_len:
+                max_in_len = int(in_len.max().item()) if n else 0
+            cap1 = compress_bound(max_in_len, literal, dictionary_reset)
+            out_cap_t = torch.full((n,), cap1, dtype=torch.int32, device=dev)
+            out_off_t = torch.arange(n, dtype=torch.int64, device=dev) * cap1
+            total = n * cap1
+        else:
+            out_cap_t = out_cap.to(device=dev, dtype=torch.int32)
+            out_off_t = torch.cumsum(out_cap_t.to(torch.int64), 0) - out_cap_t.to(torch.int64)
+            total = int(out_cap_t.to(torch.int64).sum().item())
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+        out_len_t = torch.empty(n, dtype=torch.int32, device=dev)
+        status_t = torch.empty(n, dtype=torch.int8, device=dev)
+        dict_t = None
+        if dictionary is not None:
+            dict_t = dictionary if _is_torch(dictionary) else torch.frombuffer(bytearray(dictionary), dtype=torch.uint8).to(dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.tamp_batch_compress(C.byref(conf), _ptr(dict_t), _ptr(data), _ptr(in_off.to(torch.int64)),
+                                     _ptr(in_len.to(torch.int32)), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
+                                     _ptr(out_len_t), _ptr(status_t), n, int(max_in_len), _lib.MEM_DEVICE,
+                                     dev.index or 0, C.c_void_p(st))
+        _lib.check_launch(rc)
+        ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
+        return BatchResult(out, out_off_t, out_len_t, status_t, None, ms)
+
+    if in_off is None:
+        flat, in_off, in_len = pack_streams(data)
+    else:
+        flat = _np_u8(data)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    n = len(in_len)
+    if out_cap is None:
+        out_cap = np.array([compress_bound(int(x), literal, dictionary_reset) for x in in_len], dtype=np.uint32)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    out_off, total = _slab_offsets(out_cap)
+    out = np.zeros(total + 1, dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.int8)
+    d = _np_u8(dictionary) if dictionary is not None else None
+    rc = lib.tamp_batch_compress(C.byref(conf), _ptr(d), _ptr(flat if flat.size else np.zeros(1, np.uint8)),
+                                 _ptr(in_off), _ptr(in_len), _ptr(out), _ptr(out_off), _ptr(out_cap), _ptr(out_len),
+                                 _ptr(status), n, int(max_in_len), _lib.MEM_HOST, device,
+                                 C.c_void_p(stream) if stream else None)
+    _lib.check_launch(rc)
+    ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
+    return BatchResult(out, out_off, out_len, status, None, ms)
+
+
+def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None, max_window_bits: int = 15,
+                     device: int = 0, stream=None, timing: bool = False) -> BatchResult:
+    """Decompress many independent ``.tamp`` streams in one launch (configuration read from each header).
+
+    ``out_cap`` (int or per-stream array) bounds each stream's output.  ``status[i]`` is the reference's code:
+    2 (INPUT_EXHAUSTED) on normal completion, 1 (OUTPUT_FULL) if ``out_cap[i]`` was reached with work left,
+    -4 / -3 for malformed input.
+    """
+    lib = _lib.load()
+    lib.tamp_amd_set_timing(1 if timing else 0)
+    if _is_torch(data):
+        import torch
+
+        n = int(in_len.numel())
+        dev = data.device
+        if isinstance(out_cap, int):
+            out_cap_t = torch.full((n,), out_cap, dtype=torch.int32, device=dev)
+            out_off_t = torch.arange(n, dtype=torch.int64, device=dev) * out_cap
+            total = n * out_cap
+        else:
+            out_cap_t = out_cap.to(device=dev, dtype=torch.int32)
+            out_off_t = torch.cumsum(out_cap_t.to(torch.int64), 0) - out_cap_t.to(torch.int64)
+            total = int(out_cap_t.to(torch.int64).sum().item())
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+        out_len_t = torch.empty(n, dtype=torch.int32, device=dev)
+        status_t = torch.empty(n, dtype=torch.int8, device=dev)
+        consumed_t = torch.empty(n, dtype=torch.int32, device=dev)
+        dict_t, dict_len = None, 0
+        if dictionary is not None:
+            dict_t = dictionary if _is_torch(dictionary) else torch.frombuffer(bytearray(dictionary), dtype=torch.uint8).to(dev)
+            dict_len = int(dict_t.numel())
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.tamp_batch_decompress(_ptr(dict_t), dict_len, max_window_bits, _ptr(data), _ptr(in_off.to(torch.int64)),
+                                       _ptr(in_len.to(torch.int32)), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
+                                       _ptr(out_len_t), _ptr(status_t), _ptr(consumed_t), n, _lib.MEM_DEVICE,
+                                       dev.index or 0, C.c_void_p(st))
+        _lib.check_launch(rc)
+        ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
+        return BatchResult(out, out_off_t, out_len_t, status_t, consumed_t, ms)
+
+    if in_off is None:
+        flat, in_off, in_len = pack_streams(data)
+    else:
+        flat = _np_u8(data)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    n = len(in_len)
+    if isinstance(out_cap, int):
+        out_cap = np.full(n, out_cap, dtype=np.uint32)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    out_off, total = _slab_offsets(out_cap)
+    out = np.zeros(total + 1, dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.int8)
+    consumed = np.zeros(n, dtype=np.uint32)
+    d = _np_u8(dictionary) if dictionary is not None else None
+    rc = lib.tamp_batch_decompress(_ptr(d), len(d) if d is not None else 0, max_window_bits,
+                                   _ptr(flat if flat.size else np.zeros(1, np.uint8)), _ptr(in_off), _ptr(in_len),
+                                   _ptr(out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
+                                   _ptr(consumed), n, _lib.MEM_HOST, device, C.c_void_p(stream) if stream else None)
+    _lib.check_launch(rc)
+    ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
+    return BatchResult(out, out_off, out_len, status, consumed, ms)

@@ -1,0 +1,438 @@
+// tamp_capi.hip -- the C ABI of include/tamp_amd.h over the gfx950 kernels.
+//
+// Thin host shim: argument checks, H2D/D2H staging for host buffers, launch geometry, the seeded
+// default dictionaries (tamp/_c_src/tamp/common.c:18-52, computed once per device and kept in HBM),
+// and the hipEvent timing hook bench.py reads.  All codec work happens in the kernels; there is no
+// CPU code path for it.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <mutex>
+#include <vector>
+#include <cstring>
+
+#include "tamp_amd.h"
+#include "tamp_compress_kernel.hpp"
+#include "tamp_decompress_kernel.hpp"
+
+using namespace tamp_amd;
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+constexpr size_t kSeedTable = (size_t)1 << 15;
+
+struct DeviceCtx {
+    bool ready = false;
+    int cu_count = 0;
+    size_t lds_per_block = 0;
+    uint8_t* seed_dicts = nullptr;  // 3 x 32 KiB: literal<=5, ==6, >=7
+    uint8_t* scratch = nullptr;     // decoder window slots
+    size_t scratch_bytes = 0;
+};
+
+DeviceCtx g_ctx[kMaxDevices];
+std::mutex g_mu;
+
+thread_local bool t_timing = false;
+thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+thread_local bool t_ev_valid = false;
+
+thread_local char t_last_error[512] = "";
+
+#define HIP_OK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            snprintf(t_last_error, sizeof t_last_error, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,     \
+                     hipGetErrorString(_e));                                                              \
+            return TAMP_AMD_NO_DEVICE;                                                                    \
+        }                                                                                                 \
+    } while (0)
+
+void seed_dictionary_host(unsigned char* buf, size_t size, uint8_t literal) {
+    // common.c:18-52: xorshift32 from 3758097560, one draw per 8 bytes, nibble selects from a 16-entry table.
+    static const char text16[] = " etaoinshrdlcumw";
+    static const unsigned char markup16[16] = {' ', 0, '0', 'e', 'i', '>', 't', 'o', '<', 'a', 'n', 's', '\n', 'r', '/', '.'};
+    unsigned char table[16];
+    for (int k = 0; k < 16; k++)
+        table[k] = literal <= 5 ? (unsigned char)(text16[k] & 0x1F)
+                                : (literal == 6 ? (unsigned char)(text16[k] & 0x3F) : markup16[k]);
+    uint32_t s = 3758097560u, draw = 0;
+    for (size_t i = 0; i < size; i++) {
+        if ((i & 7) == 0) {
+            s ^= s << 13;
+            s ^= s >> 17;
+            s ^= s << 5;
+            draw = s;
+        }
+        buf[i] = table[draw & 15];
+        draw >>= 4;
+    }
+}
+
+int get_ctx(int device, DeviceCtx** out) {
+    if (device < 0 || device >= kMaxDevices) return TAMP_AMD_BAD_ARGUMENT;
+    int count = 0;
+    HIP_OK(hipGetDeviceCount(&count));
+    if (device >= count) {
+        snprintf(t_last_error, sizeof t_last_error, "device %d requested, %d visible", device, count);
+        return TAMP_AMD_NO_DEVICE;
+    }
+    HIP_OK(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_mu);
+    DeviceCtx& c = g_ctx[device];
+    if (!c.ready) {
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, device));
+        c.cu_count = prop.multiProcessorCount;
+        c.lds_per_block = prop.sharedMemPerBlock;
+        std::vector<unsigned char> host(3 * kSeedTable);
+        seed_dictionary_host(host.data() + 0 * kSeedTable, kSeedTable, 5);
+        seed_dictionary_host(host.data() + 1 * kSeedTable, kSeedTable, 6);
+        seed_dictionary_host(host.data() + 2 * kSeedTable, kSeedTable, 8);
+        HIP_OK(hipMalloc(&c.seed_dicts, 3 * kSeedTable));
+        HIP_OK(hipMemcpy(c.seed_dicts, host.data(), 3 * kSeedTable, hipMemcpyHostToDevice));
+        c.ready = true;
+    }
+    *out = &c;
+    return TAMP_OK;
+}
+
+struct DevBuf {  // RAII device allocation for host-memory calls
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+void timing_begin(hipStream_t st) {
+    t_ev_valid = false;
+    if (!t_timing) return;
+    if (!t_ev0) {
+        (void)hipEventCreate(&t_ev0);
+        (void)hipEventCreate(&t_ev1);
+    }
+    (void)hipEventRecord(t_ev0, st);
+}
+void timing_end(hipStream_t st) {
+    if (!t_timing) return;
+    (void)hipEventRecord(t_ev1, st);
+    t_ev_valid = true;
+}
+
+uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
+    uint32_t blk = max_in_len ? align_up(max_in_len, 16) : 4096;
+    if (blk > 4096) blk = 4096;
+    if (blk < 64) blk = 64;
+    while (W + blk > 65536) blk >>= 1;  // 16-bit buffer positions
+    return blk;
+}
+
+int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
+                    const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
+                    const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, size_t n_streams,
+                    uint32_t max_in_len, hipStream_t st) {
+    if (n_streams == 0) return TAMP_OK;
+    CompressArgs a;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
+    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
+    a.wbits = conf->window, a.lbits = conf->literal, a.extended = conf->extended != 0;
+    a.dict_reset = conf->dictionary_reset != 0;
+    // header byte, compressor.c:236-241
+    a.header = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) |
+                         ((conf->use_custom_dictionary != 0) << 2) | ((conf->extended != 0) << 1) |
+                         (conf->dictionary_reset != 0));
+    if (conf->use_custom_dictionary) {
+        a.dict = d_dict;
+    } else {
+        // compressor.c:224-225: non-extended streams always use the literal-8 table
+        const int lit = conf->extended ? conf->literal : 8;
+        a.dict = ctx->seed_dicts + (lit <= 5 ? 0 : (lit == 6 ? 1 : 2)) * kSeedTable;
+    }
+    a.n_streams = (uint32_t)n_streams;
+    const uint32_t W = 1u << conf->window;
+    a.blk = pick_block(W, max_in_len);
+    const CompressLds L(W, a.blk);
+    if (L.total > ctx->lds_per_block) return TAMP_AMD_BAD_ARGUMENT;
+    const uint32_t threads = a.blk >= 1024 ? 256 : 64;
+    const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_compress_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+    timing_begin(st);
+    hipLaunchKernelGGL(tamp_compress_kernel, dim3(grid), dim3(threads), L.total, st, a);
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
+int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
+                      const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
+                      const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
+                      size_t n_streams, hipStream_t st) {
+    if (n_streams == 0) return TAMP_OK;
+    const uint32_t threads = 256;
+    const uint8_t slot_bits = (max_wbits >= 8 && max_wbits <= 15) ? max_wbits : 8;
+    const size_t slot = (size_t)1 << slot_bits;
+    // resident lanes: enough to fill the chip, bounded by a 1 GiB window slab
+    size_t lanes = (size_t)ctx->cu_count * 2048;
+    const size_t budget = (size_t)1 << 30;
+    if (lanes * slot > budget) lanes = budget / slot;
+    if (lanes > n_streams) lanes = n_streams;
+    const uint32_t grid = (uint32_t)((lanes + threads - 1) / threads);
+    const size_t need = (size_t)grid * threads * slot;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (ctx->scratch_bytes < need) {
+            if (ctx->scratch) {
+                HIP_OK(hipDeviceSynchronize());
+                HIP_OK(hipFree(ctx->scratch));
+                ctx->scratch = nullptr;
+                ctx->scratch_bytes = 0;
+            }
+            HIP_OK(hipMalloc(&ctx->scratch, need));
+            ctx->scratch_bytes = need;
+        }
+    }
+    DecompressArgs a;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
+    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
+    a.in_consumed = d_consumed;
+    a.dict = d_dict, a.dict_len = (uint32_t)(dict_len > 0xFFFFFFFFu ? 0xFFFFFFFFu : dict_len);
+    a.seed_dicts = ctx->seed_dicts;
+    a.scratch = ctx->scratch;
+    a.n_streams = (uint32_t)n_streams;
+    a.max_wbits = max_wbits;
+    if (!(max_wbits >= 8 && max_wbits <= 15)) a.scratch = ctx->scratch;  // kernel reports INVALID_CONF per stream
+    timing_begin(st);
+    hipLaunchKernelGGL(tamp_decompress_kernel, dim3(grid), dim3(threads), 0, st, a);
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
+bool conf_valid(const TampAmdConf* c) {
+    return c && c->window >= 8 && c->window <= 15 && c->literal >= 5 && c->literal <= 8;  // compressor.c:208-209
+}
+
+}  // namespace
+
+extern "C" {
+
+void tamp_initialize_dictionary(unsigned char* buffer, size_t size, uint8_t literal) {
+    seed_dictionary_host(buffer, size, literal);
+}
+
+int8_t tamp_compute_min_pattern_size(uint8_t window, uint8_t literal) {
+    return (int8_t)min_pattern_size(window, literal);
+}
+
+size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset) {
+    return 1 + (dictionary_reset ? 1 : 0) + (n * ((size_t)literal + 1) + 7) / 8;
+}
+
+int tamp_amd_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char* tamp_amd_version(void) { return "tamp_amd 0.1 (gfx950)"; }
+
+const char* tamp_amd_last_error(void) { return t_last_error; }
+
+void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
+
+float tamp_amd_last_kernel_ms(void) {
+    if (!t_ev_valid) return -1.0f;
+    if (hipEventSynchronize(t_ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, t_ev0, t_ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, const uint8_t* in, const uint64_t* in_off,
+                        const uint32_t* in_len, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                        uint32_t* out_len, int8_t* status, size_t n_streams, uint32_t max_in_len, int mem, int device,
+                        void* stream) {
+    if (!conf || (n_streams && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)))
+        return TAMP_AMD_BAD_ARGUMENT;
+    if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    if (conf->lazy_matching) return TAMP_AMD_BAD_ARGUMENT;  // not in this release
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool bad_conf = !conf_valid(conf) || (conf->use_custom_dictionary && !dictionary);
+
+    if (mem == TAMP_AMD_MEM_DEVICE) {
+        if (bad_conf) {  // tamp_compressor_init would have returned TAMP_INVALID_CONF for every stream
+            HIP_OK(hipMemsetAsync(status, (uint8_t)(int8_t)TAMP_INVALID_CONF, n_streams, st));
+            HIP_OK(hipMemsetAsync(out_len, 0, n_streams * sizeof(uint32_t), st));
+            return TAMP_OK;
+        }
+        return launch_compress(ctx, conf, dictionary, in, in_off, in_len, out, out_off, out_cap, out_len, status,
+                               n_streams, max_in_len, st);
+    }
+
+    // ---- host memory: stage, run, copy back ----
+    if (bad_conf) {
+        for (size_t i = 0; i < n_streams; i++) status[i] = TAMP_INVALID_CONF, out_len[i] = 0;
+        return TAMP_OK;
+    }
+    if (n_streams == 0) return TAMP_OK;
+    uint64_t in_end = 0, out_end = 0;
+    uint32_t maxlen = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        if (in_off[i] + in_len[i] > in_end) in_end = in_off[i] + in_len[i];
+        if (out_off[i] + out_cap[i] > out_end) out_end = out_off[i] + out_cap[i];
+        if (in_len[i] > maxlen) maxlen = in_len[i];
+    }
+    if (!max_in_len) max_in_len = maxlen ? maxlen : 16;
+    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_dict;
+    HIP_OK(d_in.alloc(in_end + 64));
+    HIP_OK(d_out.alloc(out_end));
+    HIP_OK(d_io.alloc(n_streams * 8));
+    HIP_OK(d_il.alloc(n_streams * 4));
+    HIP_OK(d_oo.alloc(n_streams * 8));
+    HIP_OK(d_oc.alloc(n_streams * 4));
+    HIP_OK(d_ol.alloc(n_streams * 4));
+    HIP_OK(d_st.alloc(n_streams));
+    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_streams * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_streams * 4, hipMemcpyHostToDevice, st));
+    if (conf->use_custom_dictionary) {
+        HIP_OK(d_dict.alloc((size_t)1 << conf->window));
+        HIP_OK(hipMemcpyAsync(d_dict.p, dictionary, (size_t)1 << conf->window, hipMemcpyHostToDevice, st));
+    }
+    rc = launch_compress(ctx, conf, d_dict.as<uint8_t>(), d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(),
+                         d_out.as<uint8_t>(), d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(),
+                         d_st.as<int8_t>(), n_streams, max_in_len, st);
+    if (rc != TAMP_OK) return rc;
+    if (out_end) HIP_OK(hipMemcpyAsync(out, d_out.p, out_end, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(status, d_st.p, n_streams, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return TAMP_OK;
+}
+
+int tamp_batch_decompress(const uint8_t* dictionary, size_t dictionary_len, uint8_t max_window_bits, const uint8_t* in,
+                          const uint64_t* in_off, const uint32_t* in_len, uint8_t* out, const uint64_t* out_off,
+                          const uint32_t* out_cap, uint32_t* out_len, int8_t* status, uint32_t* in_consumed,
+                          size_t n_streams, int mem, int device, void* stream) {
+    if (n_streams && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return TAMP_AMD_BAD_ARGUMENT;
+    if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!dictionary) dictionary_len = 0;
+
+    if (mem == TAMP_AMD_MEM_DEVICE)
+        return launch_decompress(ctx, dictionary, dictionary_len, max_window_bits, in, in_off, in_len, out, out_off,
+                                 out_cap, out_len, status, in_consumed, n_streams, st);
+
+    if (n_streams == 0) return TAMP_OK;
+    uint64_t in_end = 0, out_end = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        if (in_off[i] + in_len[i] > in_end) in_end = in_off[i] + in_len[i];
+        if (out_off[i] + out_cap[i] > out_end) out_end = out_off[i] + out_cap[i];
+    }
+    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_ic, d_dict;
+    HIP_OK(d_in.alloc(in_end + 64));
+    HIP_OK(d_out.alloc(out_end));
+    HIP_OK(d_io.alloc(n_streams * 8));
+    HIP_OK(d_il.alloc(n_streams * 4));
+    HIP_OK(d_oo.alloc(n_streams * 8));
+    HIP_OK(d_oc.alloc(n_streams * 4));
+    HIP_OK(d_ol.alloc(n_streams * 4));
+    HIP_OK(d_ic.alloc(n_streams * 4));
+    HIP_OK(d_st.alloc(n_streams));
+    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_streams * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_streams * 4, hipMemcpyHostToDevice, st));
+    if (dictionary_len) {
+        const size_t use = dictionary_len < kSeedTable ? dictionary_len : kSeedTable;
+        HIP_OK(d_dict.alloc(use));
+        HIP_OK(hipMemcpyAsync(d_dict.p, dictionary, use, hipMemcpyHostToDevice, st));
+        dictionary_len = use;
+    }
+    rc = launch_decompress(ctx, dictionary_len ? d_dict.as<uint8_t>() : nullptr, dictionary_len, max_window_bits,
+                           d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(), d_out.as<uint8_t>(),
+                           d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(), d_st.as<int8_t>(),
+                           d_ic.as<uint32_t>(), n_streams, st);
+    if (rc != TAMP_OK) return rc;
+    if (out_end) HIP_OK(hipMemcpyAsync(out, d_out.p, out_end, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(status, d_st.p, n_streams, hipMemcpyDeviceToHost, st));
+    if (in_consumed) HIP_OK(hipMemcpyAsync(in_consumed, d_ic.p, n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return TAMP_OK;
+}
+
+tamp_res tamp_amd_compress(const TampAmdConf* conf, const unsigned char* dictionary, unsigned char* output,
+                           size_t output_size, size_t* output_written_size, const unsigned char* input,
+                           size_t input_size, int device) {
+    if (output_written_size) *output_written_size = 0;
+    if (input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    const uint64_t zero = 0;
+    const uint32_t ilen = (uint32_t)input_size;
+    const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+    uint32_t olen = 0;
+    int8_t st = TAMP_ERROR;
+    static const unsigned char empty = 0;
+    int rc = tamp_batch_compress(conf, dictionary, input ? input : &empty, &zero, &ilen, output, &zero, &ocap, &olen,
+                                 &st, 1, ilen, TAMP_AMD_MEM_HOST, device, nullptr);
+    if (rc != TAMP_OK) return (tamp_res)rc;
+    if (output_written_size) *output_written_size = olen;
+    return st;
+}
+
+tamp_res tamp_amd_decompress(const unsigned char* dictionary, size_t dictionary_len, unsigned char* output,
+                             size_t output_size, size_t* output_written_size, const unsigned char* input,
+                             size_t input_size, size_t* input_consumed_size, int device) {
+    if (output_written_size) *output_written_size = 0;
+    if (input_consumed_size) *input_consumed_size = 0;
+    if (input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    const uint64_t zero = 0;
+    const uint32_t ilen = (uint32_t)input_size;
+    const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+    uint32_t olen = 0, consumed = 0;
+    int8_t st = TAMP_ERROR;
+    static const unsigned char empty = 0;
+    int rc = tamp_batch_decompress(dictionary, dictionary_len, 15, input ? input : &empty, &zero, &ilen, output, &zero,
+                                   &ocap, &olen, &st, &consumed, 1, TAMP_AMD_MEM_HOST, device, nullptr);
+    if (rc != TAMP_OK) return (tamp_res)rc;
+    if (output_written_size) *output_written_size = olen;
+    if (input_consumed_size) *input_consumed_size = consumed;
+    return st;
+}
+
+tamp_res tamp_amd_read_header(TampAmdConf* conf, const unsigned char* input, size_t input_size,
+                              size_t* input_consumed_size) {
+    // decompressor.c:276-297
+    if (input_consumed_size) *input_consumed_size = 0;
+    if (input_size == 0) return TAMP_INPUT_EXHAUSTED;
+    const size_t hs = 1 + (input[0] & 1);
+    if (input_size < hs) return TAMP_INPUT_EXHAUSTED;
+    if (hs >= 2 && input[1]) return TAMP_INVALID_CONF;
+    std::memset(conf, 0, sizeof(*conf));
+    conf->window = (uint8_t)(((input[0] >> 5) & 7) + 8);
+    conf->literal = (uint8_t)(((input[0] >> 3) & 3) + 5);
+    conf->use_custom_dictionary = (input[0] >> 2) & 1;
+    conf->extended = (input[0] >> 1) & 1;
+    conf->dictionary_reset = input[0] & 1;
+    if (input_consumed_size) *input_consumed_size = hs;
+    return TAMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// tamp_common.hpp -- constants and small device helpers shared by the gfx950 kernels.
+//
+// Format facts restated from the reference (paths relative to its repository root):
+//   prefix code for match lengths ......... tamp/_c_src/tamp/compressor.c:33-36
+//   RLE / extended-match token layout ..... tamp/_c_src/tamp/compressor.c:257-263,342-415
+//   tamp_res status numbering ............. tamp/_c_src/tamp/common.h:145-168
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tamp_amd {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr uint32_t kRing = 16;     // the reference's input ring: look-ahead of one parse step
+constexpr uint32_t kPendMax = 256; // >= 241 (longest RLE run) and >= 134 (longest extended match)
+constexpr uint32_t kRleMax = 241;  // (14 << 4) + 15 + 2
+constexpr uint32_t kRleWindowMax = 8;
+constexpr uint32_t kExtExtraMax = 120;  // (14 << 3) + 7 + 1
+constexpr int kSymRle = 12, kSymExt = 13, kSymFlush = 14;
+
+enum : int8_t {
+    kOk = 0,
+    kOutputFull = 1,
+    kInputExhausted = 2,
+    kError = -1,
+    kExcessBits = -2,
+    kInvalidConf = -3,
+    kOob = -4,
+};
+
+// Match-length prefix code: code without the leading 0 flag, length including it.
+__device__ __constant__ uint8_t d_code[15] = {0x00, 0x03, 0x08, 0x0b, 0x14, 0x24, 0x26, 0x2b,
+                                              0x4b, 0x54, 0x94, 0x95, 0xaa, 0x27, 0xab};
+__device__ __constant__ uint8_t d_nbits[15] = {2, 3, 5, 5, 6, 7, 7, 7, 8, 8, 9, 9, 9, 7, 9};
+
+__host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) & ~(a - 1); }
+
+__host__ __device__ inline int min_pattern_size(int window, int literal) {
+    return 2 + (window > 10 + 2 * (literal - 5));
+}
+
+// 4 bytes at an arbitrary LDS byte offset: two aligned dwords funnel-shifted by the byte phase.
+__device__ __forceinline__ uint32_t lds_u32_unaligned(const uint8_t* base, uint32_t off) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3u);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+}  // namespace tamp_amd
