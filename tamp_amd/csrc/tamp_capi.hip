@@ -39,6 +39,7 @@ thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
 thread_local bool t_ev_valid = false;
 
 thread_local char t_last_error[512] = "";
+unsigned long long* g_prof = nullptr;  // -DTAMP_PROF builds: device buffer of per-phase cycle sums
 
 #define HIP_OK(expr)                                                                                      \
     do {                                                                                                  \
@@ -154,6 +155,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
         a.dict = ctx->seed_dicts + (lit <= 5 ? 0 : (lit == 6 ? 1 : 2)) * kSeedTable;
     }
     a.n_streams = (uint32_t)n_streams;
+    a.prof = g_prof;
     const uint32_t W = 1u << conf->window;
     a.blk = pick_block(W, max_in_len);
     const CompressLds L(W, a.blk);
@@ -243,6 +245,22 @@ int tamp_amd_device_count(void) {
 const char* tamp_amd_version(void) { return "tamp_amd 0.1 (gfx950)"; }
 
 const char* tamp_amd_last_error(void) { return t_last_error; }
+
+#ifdef TAMP_PROF
+// debug-only: per-phase cycle counters (not part of the public header)
+int tamp_amd_prof_read(unsigned long long* out6) {
+    if (!g_prof) {
+        if (hipMalloc(&g_prof, 64) != hipSuccess) return -1;
+        (void)hipMemset(g_prof, 0, 64);
+        for (int i = 0; i < 6; i++) out6[i] = 0;
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out6, g_prof, 48, hipMemcpyDeviceToHost);
+    (void)hipMemset(g_prof, 0, 64);
+    return 0;
+}
+#endif
 
 void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
 

@@ -41,6 +41,7 @@ struct CompressArgs {
     uint32_t n_streams;
     uint32_t blk;  // epoch block: positions matched per epoch (multiple of 16)
     uint8_t wbits, lbits, extended, header, dict_reset;
+    unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
 };
 
 // LDS carve-up, shared by the host launcher and the kernel.
@@ -381,6 +382,13 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
         if (a.dict_reset) wk.put(0, 8);
 
         uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters, uniform over the workgroup
+#ifdef TAMP_PROF
+        unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long pc = __builtin_readcyclecounter();
+#define TAMP_PROF_MARK(i) do { __syncthreads(); unsigned long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } while (0)
+#else
+#define TAMP_PROF_MARK(i) do { } while (0)
+#endif
         for (;;) {
             // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
             const uint32_t left = n - e_p0;
@@ -401,6 +409,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
             }
             for (uint32_t k = tid; k < kHashBuckets; k += nt) cnt[k] = 0;
             __syncthreads();
+            TAMP_PROF_MARK(0);
 
             // ---------------- index: counting sort of buffer positions by bigram hash ----------------
             // positions c in [0, NE): every candidate any query of this block may need
@@ -452,6 +461,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                 }
             }
             __syncthreads();
+            TAMP_PROF_MARK(1);
             // now bucket h = ent[(h ? cnt[h-1] : 0) .. cnt[h])
 
             // ---------------- match phase: find_best_match for every position of the block ----------------
@@ -495,6 +505,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                 bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
             }
             __syncthreads();
+            TAMP_PROF_MARK(2);
 
             // ---------------- walk: wave 0 ----------------
             if (wave == 0) {
@@ -565,6 +576,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                 if (lane == 0) ctl[0] = done;
             }
             __syncthreads();
+            TAMP_PROF_MARK(3);
             if (ctl[0]) break;
             const uint32_t shift = ctl[1];
             e_p0 = ctl[2];
@@ -582,6 +594,9 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                 }
             }
         }
+#ifdef TAMP_PROF
+        if (tid == 0 && a.prof) for (int i = 0; i < 6; i++) atomicAdd(&a.prof[i], pt[i]);
+#endif
         __syncthreads();  // ctl / LDS reuse by the next stream
     }
 }
