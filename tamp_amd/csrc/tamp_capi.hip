@@ -126,10 +126,12 @@ void timing_end(hipStream_t st) {
 }
 
 uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
-    uint32_t blk = max_in_len ? align_up(max_in_len, 16) : 4096;
-    if (blk > 4096) blk = 4096;
+    // positions matched per epoch: the whole stream when it is short, else 2048 (LDS ~30 KB at W=1024,
+    // five workgroups per CU); always a multiple of 64 (the walk chases 64 positions per register)
+    uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
+    if (blk > 2048) blk = 2048;
     if (blk < 64) blk = 64;
-    while (W + blk > 65536) blk >>= 1;  // 16-bit buffer positions
+    while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
     return blk;
 }
 
@@ -158,14 +160,19 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.prof = g_prof;
     const uint32_t W = 1u << conf->window;
     a.blk = pick_block(W, max_in_len);
-    const CompressLds L(W, a.blk);
-    if (L.total > ctx->lds_per_block) return TAMP_AMD_BAD_ARGUMENT;
+    const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
+    const CompressLds L(W, a.blk, packed);
+    if (L.total > ctx->lds_per_block) {
+        snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
+        return TAMP_AMD_BAD_ARGUMENT;
+    }
     const uint32_t threads = a.blk >= 1024 ? 256 : 64;
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_compress_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+    auto kernel = packed ? tamp_compress_kernel<true> : tamp_compress_kernel<false>;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)L.total));
     timing_begin(st);
-    hipLaunchKernelGGL(tamp_compress_kernel, dim3(grid), dim3(threads), L.total, st, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), L.total, st, a);
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;

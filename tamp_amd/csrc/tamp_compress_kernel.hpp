@@ -10,15 +10,21 @@
 //     written to the window; the live window is its last W bytes, and input is appended behind it:
 //         ebuf[0..W)   window at epoch start (oldest first)      ebuf[W+k] = input[p0+k]
 //         window index of ebuf[c] = (wp_e + c) mod W
-//   * MATCH PHASE (all threads): under the speculation "every consumed byte was written" the window
-//     seen at input position q is ebuf[q..q+W) no matter how earlier bytes were parsed, so
-//     find_best_match is evaluated for every position of the block at once.  Candidates come from a
-//     counting-sorted bigram index over the buffer (the reference needs a 2-byte prefix hit too),
-//     so work per position is O(#positions sharing the bigram), not O(W).
-//   * WALK (wave 0, all lanes computing the same scalars): the greedy parse, RLE / extended-match
-//     state machine and bit packing.  Tokens that write fewer bytes than they consume
-//     (compressor.c:352-358,404-410) break the speculation; the next find_best_match request then
-//     re-bases the buffer and starts a new epoch.
+//   * INDEX (all threads): counting sort of buffer positions by bigram (find_best_match needs a 2-byte
+//     prefix hit), scattered tile by tile so every bucket is position-ordered at tile granularity.
+//     An entry carries the position, the rest of the bigram and the next two bytes, so that 2- and
+//     3-byte candidates are classified without touching the buffer.
+//   * MATCH (all threads, one position per lane): under the speculation "every consumed byte was
+//     written" the window seen at input position q is ebuf[q..q+W) however earlier bytes were parsed,
+//     so find_best_match is evaluated for every position of the block at once; each lane walks only
+//     the in-window part of its bucket.  Work per position is O(#window positions sharing the bigram).
+//   * WALK (wave 0): the greedy parse.  Plain steps (literal / match token, the ~97 % case) are chased
+//     64 positions at a time out of a register with v_readlane; only RLE / extended-match situations
+//     (compressor.c:437-525) run the scalar state machine.  The walk emits a token list, not bits.
+//   * EMIT (all threads): token bit strings from the list, a workgroup prefix sum of their lengths,
+//     and an MSb-first scatter into an LDS bit buffer that is flushed to HBM.
+//   * Tokens that write fewer bytes than they consume (compressor.c:352-358,404-410) break the
+//     speculation; the next find_best_match request re-bases the buffer and starts a new epoch.
 #pragma once
 #include "tamp_common.hpp"
 
@@ -26,7 +32,8 @@ namespace tamp_amd {
 
 constexpr uint32_t kHashBits = 11;
 constexpr uint32_t kHashBuckets = 1u << kHashBits;
-constexpr uint32_t kObuf = 1024;  // output staging bytes in LDS (multiple of 4)
+constexpr uint32_t kRemBits = 16 - kHashBits;  // bigram bits not implied by the bucket number
+constexpr uint32_t kSlowCap = 256;             // explicit (non-derivable) token pieces per walk segment
 
 struct CompressArgs {
     const uint8_t* in;
@@ -39,7 +46,7 @@ struct CompressArgs {
     int8_t* status;
     const uint8_t* dict;  // 1<<wbits bytes: the custom dictionary or the seeded default
     uint32_t n_streams;
-    uint32_t blk;  // epoch block: positions matched per epoch (multiple of 16)
+    uint32_t blk;  // epoch block: positions matched per epoch (multiple of 64)
     uint8_t wbits, lbits, extended, header, dict_reset;
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
 };
@@ -47,99 +54,138 @@ struct CompressArgs {
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
     uint32_t ebuf, cnt, ent, blen, bidx, obuf, ctl, total;
-    __host__ __device__ CompressLds(uint32_t W, uint32_t blk) {
+    uint32_t tokcap, obuf_words;
+    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed) {
         uint32_t o = 0;
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
-        cnt = o;
-        o += kHashBuckets * 4;
-        ent = o;
-        o += align_up((W + blk) * 2, 16);
+        cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
+        o += kHashBuckets * 2;
+        tokcap = blk + kPendMax + kRing + 80;
+        ent = o;  // (W + blk) index entries (u32 packed, or u16 position-only for the largest windows);
+                  // the walk reuses the space for the token list (tokcap x u16)
+        {
+            const uint32_t index_bytes = (W + blk + 16) * (packed ? 4u : 2u), list_bytes = tokcap * 2;
+            o += align_up(index_bytes > list_bytes ? index_bytes : list_bytes, 16);
+        }
         blen = o;
-        o += align_up(blk, 16);
+        o += align_up(blk + 128, 16);
         bidx = o;
         o += align_up(blk * 2, 16);
+        obuf_words = ((blk + kPendMax + kRing + 64) * 9 + kSlowCap * 25) / 32 + 8;
         obuf = o;
-        o += kObuf;
+        o += align_up(obuf_words * 4, 16);
         ctl = o;
         o += 64;
         total = o;
     }
 };
 
-__device__ __forceinline__ uint32_t bigram_hash(uint32_t pair16) {
-    return ((pair16 * 40503u) >> (16 - kHashBits)) & (kHashBuckets - 1);
+// Match-length prefix code (compressor.c:33-36) packed into immediates: no memory access on the hot path.
+constexpr uint64_t pack_bytes(const uint8_t* v, int first, int count) {
+    uint64_t r = 0;
+    for (int i = 0; i < count; i++) r |= (uint64_t)v[first + i] << (8 * i);
+    return r;
+}
+constexpr uint8_t kCodeTab[15] = {0x00, 0x03, 0x08, 0x0b, 0x14, 0x24, 0x26, 0x2b, 0x4b, 0x54, 0x94, 0x95, 0xaa, 0x27, 0xab};
+constexpr uint8_t kNbitsTab[15] = {2, 3, 5, 5, 6, 7, 7, 7, 8, 8, 9, 9, 9, 7, 9};  // incl. the flag bit
+constexpr uint64_t pack_nibbles(const uint8_t* v, int count) {
+    uint64_t r = 0;
+    for (int i = 0; i < count; i++) r |= (uint64_t)v[i] << (4 * i);
+    return r;
+}
+constexpr uint64_t kCodeLo = pack_bytes(kCodeTab, 0, 8), kCodeHi = pack_bytes(kCodeTab, 8, 7);
+constexpr uint64_t kNbitsPacked = pack_nibbles(kNbitsTab, 15);
+__device__ __forceinline__ uint32_t tok_code(uint32_t i) {
+    return (uint32_t)((i < 8 ? kCodeLo >> (8 * i) : kCodeHi >> (8 * (i - 8))) & 0xFF);
+}
+__device__ __forceinline__ uint32_t tok_nbits(uint32_t i) { return (uint32_t)(kNbitsPacked >> (4 * i)) & 15; }
+
+// 16-bit bijective mix of a bigram: top kHashBits select the bucket, the rest ride in the entry.
+__device__ __forceinline__ uint32_t mix16(uint32_t pair16) { return (pair16 * 40503u) & 0xFFFFu; }
+// entry payload from 4 little-endian bytes b0..b3 at a position: rem | b2 | low bits of b3, in bits 16..31
+__device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix) {
+    return ((mix & ((1u << kRemBits) - 1)) << 16) | (((bytes4 >> 16) & 0xFFu) << (16 + kRemBits)) |
+           ((bytes4 >> 24) << (24 + kRemBits));
+}
+
+// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].
+__device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
+    const uint32_t sh = c & 3u;
+    uint32_t lo = w[0], hi = w[1];
+    uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[0];
+    if (x) return (uint32_t)__builtin_ctz(x) >> 3;
+    lo = hi;
+    hi = w[2];
+    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[1];
+    if (x) return 4 + ((uint32_t)__builtin_ctz(x) >> 3);
+    lo = hi;
+    hi = w[3];
+    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[2];
+    if (x) return 8 + ((uint32_t)__builtin_ctz(x) >> 3);
+    lo = hi;
+    hi = w[4];
+    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[3];
+    if (x) return 12 + ((uint32_t)__builtin_ctz(x) >> 3);
+    return 16;
+}
+
+// Candidate whose bytes may run past the newest window byte (the ring continues with the oldest).
+__device__ __forceinline__ uint32_t prefix_len_wrapped(const uint8_t* ebuf, uint32_t c, uint32_t q, uint32_t W,
+                                                       uint32_t lim) {
+    uint32_t len = 0;
+    while (len < lim) {
+        uint32_t s = c + len;
+        if (s >= q + W) s -= W;
+        if (ebuf[s] != ebuf[W + q + len]) break;
+        len++;
+    }
+    return len;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Walk state: lives in registers of wave 0, identical in every lane.
+// Walk state: registers of wave 0, identical in every lane (lane 0 performs the LDS stores).
 // ---------------------------------------------------------------------------------------------
 struct Walk {
     uint8_t* ebuf;
     const uint8_t* blen;
     const uint16_t* bidx;
-    uint8_t* obuf;
-    uint8_t* gout;
-    uint32_t cap;
+    uint16_t* toklist;  // token list: q (derivable token at input position q) or 0x8000|k (explicit piece k)
+    uint32_t* stok;     // explicit pieces: stok[2k] = bits, stok[2k+1] = bit count
     uint32_t W, mask, wbits, lbits, minp;
     bool ext;
-    uint32_t n;       // stream length
-    uint32_t p0;      // input position of ebuf[W]
     uint32_t wp_e;    // window_pos at epoch start
     uint32_t wr, rd;  // bytes written / consumed since epoch start
-    uint32_t nvalid, blk;
+    uint32_t nvalid;
     uint32_t rle_count, ext_count, ext_pos;
-    uint64_t acc;     // pending output bits, right aligned
-    uint32_t nacc;    // < 32 between tokens
-    uint32_t opos;    // bytes staged in obuf (multiple of 4)
-    uint32_t gpos;    // bytes already copied to global
-    uint32_t tbits;   // total bits emitted
+    uint32_t ntok, ns;
     int lane;
 
+    // The walk's scalars are identical in all 64 lanes; values that come back from LDS are passed through
+    // v_readfirstlane so the compiler keeps the whole state machine on the scalar unit (s_cbranch_scc, no
+    // exec-mask juggling).
+    static __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
     __device__ __forceinline__ uint32_t wp() const { return (wp_e + wr) & mask; }
     // byte at window index i of the live window ebuf[wr .. wr+W)
-    __device__ __forceinline__ uint32_t win(uint32_t i) const { return ebuf[wr + ((i - wp()) & mask)]; }
-    __device__ __forceinline__ uint32_t inb(uint32_t k) const { return ebuf[W + rd + k]; }
+    __device__ __forceinline__ uint32_t win(uint32_t i) const { return uni(ebuf[wr + ((i - wp()) & mask)]); }
+    __device__ __forceinline__ uint32_t inb(uint32_t k) const { return uni(ebuf[W + rd + k]); }
+    // per-lane variants for the cooperative search
+    __device__ __forceinline__ uint32_t win_l(uint32_t i) const { return ebuf[wr + ((i - wp()) & mask)]; }
+    __device__ __forceinline__ uint32_t inb_l(uint32_t k) const { return ebuf[W + rd + k]; }
 
-    __device__ void flush_stage() {
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = lane; k < opos; k += kWave) {
-            uint8_t b = obuf[k];
-            if (gpos + k < cap) gout[gpos + k] = b;
-        }
-        __builtin_amdgcn_wave_barrier();
-        gpos += opos;
-        opos = 0;
-    }
-
-    // write_to_bit_buffer + partial_flush (compressor.c:49-52,65-75): MSb-first append.
+    // write_to_bit_buffer (compressor.c:49-52) becomes "append an explicit piece to the token list"
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb) {
-        acc = (acc << nb) | v;
-        nacc += nb;
-        tbits += nb;
-        if (nacc >= 32) {
-            uint32_t word = (uint32_t)(acc >> (nacc - 32));
-            if (lane == 0) *reinterpret_cast<uint32_t*>(obuf + opos) = __builtin_bswap32(word);
-            opos += 4;
-            nacc -= 32;
-            if (opos == kObuf) flush_stage();
+        if (lane == 0) {
+            stok[2 * ns] = v;
+            stok[2 * ns + 1] = nb;
+            toklist[ntok] = (uint16_t)(0x8000u | ns);
         }
+        ns++;
+        ntok++;
     }
 
-    // Move the (< 32) pending bits that form whole bytes into the staging buffer and copy it out.
-    __device__ void drain_whole_bytes() {
-        uint32_t nbytes = nacc >> 3;
-        for (uint32_t j = 0; j < nbytes; j++) {
-            uint8_t b = (uint8_t)(acc >> (nacc - 8 * (j + 1)));
-            if (lane == 0) obuf[opos + j] = b;
-        }
-        opos += nbytes;
-        nacc -= 8 * nbytes;
-        flush_stage();
-    }
-
-    // Append `cnt` bytes to the history.  `clean` = the bytes are exactly the input bytes already
-    // sitting at that place (speculation intact), so nothing has to be stored.
+    // Append `cnt` bytes to the history.  `clean` = they are exactly the input bytes already sitting there.
     template <class F>
     __device__ __forceinline__ void append(uint32_t cnt, bool clean, F byte_at) {
         if (!clean) {
@@ -154,13 +200,13 @@ struct Walk {
 
     __device__ __forceinline__ void put_exthuff(uint32_t value, uint32_t trailing) {  // compressor.c:257-263
         uint32_t ci = value >> trailing;
-        put(((uint32_t)d_code[ci] << trailing) | (value & ((1u << trailing) - 1)), (d_nbits[ci] - 1) + trailing);
+        put((tok_code(ci) << trailing) | (value & ((1u << trailing) - 1)), (tok_nbits(ci) - 1) + trailing);
     }
 
     // write_rle_token (compressor.c:342-359); the run's `count` bytes are already consumed.
     __device__ void emit_rle(uint32_t count) {
         const uint32_t sym = win((wp() - 1) & mask);
-        put(d_code[kSymRle], d_nbits[kSymRle]);
+        put(tok_code(kSymRle), tok_nbits(kSymRle));
         put_exthuff(count - 2, 4);
         uint32_t w = min(min(count, kRleWindowMax), W - wp());
         const bool clean = (wr + count == rd) && (w == count);
@@ -170,15 +216,15 @@ struct Walk {
     // write_extended_match_token (compressor.c:377-415)
     __device__ void emit_ext() {
         const uint32_t count = ext_count, pos = ext_pos;
-        put(d_code[kSymExt], d_nbits[kSymExt]);
+        put(tok_code(kSymExt), tok_nbits(kSymExt));
         put_exthuff(count - minp - 12, 3);
         put(pos, wbits);
         uint32_t w = min(count, W - wp());
         const bool clean = (wr + count == rd) && (w == count);
         const uint32_t wr0 = wr, wp0 = wp();
-        // Sources are read in the pre-token window; appended bytes land beyond it (memmove
+        // Sources are read in the pre-token window; appended bytes land beyond it (the memmove
         // semantics of tamp_window_copy, common.c:58-86, for free).
-        append(w, clean, [&](uint32_t i) { return (uint32_t)ebuf[wr0 + ((pos + i - wp0) & mask)]; });
+        append(w, clean, [&](uint32_t i) { return uni(ebuf[wr0 + ((pos + i - wp0) & mask)]); });
         ext_count = 0;
     }
 
@@ -189,13 +235,13 @@ struct Walk {
         const uint32_t nextb = inb(0);
         uint32_t key = 0;
         for (uint32_t c = pos + lane; c + cnt + 1 <= W; c += kWave) {
-            if (win(c + cnt) != nextb) continue;
+            if (win_l(c + cnt) != nextb) continue;
             uint32_t i = 0;
-            while (i < cnt && win(c + i) == win(pos + i)) i++;
+            while (i < cnt && win_l(c + i) == win_l(pos + i)) i++;
             if (i < cnt) continue;
             const uint32_t cmax = min(maxp, W - c);
             uint32_t len = cnt + 1;
-            while (len < cmax && win(c + len) == inb(len - cnt)) len++;
+            while (len < cmax && win_l(c + len) == inb_l(len - cnt)) len++;
             uint32_t k = (len << 16) | (0xFFFFu - c);
             if ((k >> 16) > (key >> 16)) key = k;  // first-longest within this lane (c ascending)
         }
@@ -208,8 +254,8 @@ struct Walk {
 
     __device__ __forceinline__ bool best(uint32_t& idx, uint32_t& len) const {
         if (wr != rd || rd >= nvalid) return false;
-        len = blen[rd];
-        idx = bidx[rd];
+        len = uni(blen[rd]) & 0x1Fu;
+        idx = uni(bidx[rd]);
         return true;
     }
 
@@ -288,68 +334,54 @@ struct Walk {
                 rd += len;
                 return kStepOk;
             }
-            put(((uint32_t)d_code[len - minp] << wbits) | idx, d_nbits[len - minp] + wbits);
+            put((tok_code(len - minp) << wbits) | idx, tok_nbits(len - minp) + wbits);
         }
         // compressor.c:651-657: the consumed bytes enter the window
         const uint32_t rd0 = rd;
         rd += len;
-        append(len, wr + len == rd, [&](uint32_t i) { return (uint32_t)ebuf[W + rd0 + i]; });
+        append(len, wr + len == rd, [&](uint32_t i) { return uni(ebuf[W + rd0 + i]); });
         return kStepOk;
     }
 };
 
-// ---------------------------------------------------------------------------------------------
-// Match phase helpers
-// ---------------------------------------------------------------------------------------------
+enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
+// ctl words
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cWave = 8 };
 
-// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].
-__device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
-    const uint32_t sh = c & 3u;
-    uint32_t lo = w[0], hi = w[1];
-    uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[0];
-    if (x) return (uint32_t)__builtin_ctz(x) >> 3;
-    lo = hi;
-    hi = w[2];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[1];
-    if (x) return 4 + ((uint32_t)__builtin_ctz(x) >> 3);
-    lo = hi;
-    hi = w[3];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[2];
-    if (x) return 8 + ((uint32_t)__builtin_ctz(x) >> 3);
-    lo = hi;
-    hi = w[4];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[3];
-    if (x) return 12 + ((uint32_t)__builtin_ctz(x) >> 3);
-    return 16;
-}
-
-// Candidate whose bytes may run past the newest window byte (ring continues with the oldest).
-__device__ __forceinline__ uint32_t prefix_len_wrapped(const uint8_t* ebuf, uint32_t c, uint32_t q, uint32_t W,
-                                                       uint32_t lim) {
-    uint32_t len = 0;
-    while (len < lim) {
-        uint32_t s = c + len;
-        if (s >= q + W) s -= W;
-        if (ebuf[s] != ebuf[W + q + len]) break;
-        len++;
-    }
-    return len;
-}
+#ifdef TAMP_PROF
+#define TAMP_PROF_MARK(i)                                     \
+    do {                                                      \
+        __syncthreads();                                      \
+        unsigned long long _n = __builtin_readcyclecounter(); \
+        pt[i] += _n - pc;                                     \
+        pc = _n;                                              \
+    } while (0)
+#else
+#define TAMP_PROF_MARK(i) \
+    do {                  \
+    } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
+// PACKED: u32 index entries (position | rest of bigram | next byte | 3 bits of the one after); otherwise u16
+// positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
+template <bool PACKED>
 __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
-    const CompressLds L(W, a.blk);
+    const CompressLds L(W, a.blk, PACKED);
     uint8_t* const ebuf = smem + L.ebuf;
-    uint32_t* const cnt = reinterpret_cast<uint32_t*>(smem + L.cnt);
-    uint16_t* const ent = reinterpret_cast<uint16_t*>(smem + L.ent);
+    uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
+    uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
+    uint32_t* const ent = reinterpret_cast<uint32_t*>(smem + L.ent);
+    uint16_t* const ent16 = reinterpret_cast<uint16_t*>(smem + L.ent);
+    uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
+    uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
     uint8_t* const blen = smem + L.blen;
     uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
-    uint8_t* const obuf = smem + L.obuf;
+    uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
     volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
 
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -358,10 +390,13 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
     const uint32_t minp = (uint32_t)min_pattern_size(a.wbits, a.lbits);
     const bool ext = a.extended != 0;
     const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
+    const uint32_t wbits = a.wbits, lbits = a.lbits;
 
     for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
+        uint8_t* const gout = a.out + a.out_off[s];
+        const uint32_t cap = a.out_cap[s];
 
         // window <- dictionary (custom, or the seeded default prepared by the host shim)
         if ((reinterpret_cast<uintptr_t>(a.dict) & 3) == 0) {
@@ -370,168 +405,227 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
         } else {
             for (uint32_t k = tid; k < W; k += nt) ebuf[k] = a.dict[k];
         }
+        // bit buffer: header byte(s) (compressor.c:236-241), rest zero
+        for (uint32_t k = tid; k < L.obuf_words; k += nt)
+            obuf[k] = k == 0 ? __builtin_bswap32((uint32_t)a.header << 24) : 0;
 
         Walk wk;
-        wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.obuf = obuf;
-        wk.gout = a.out + a.out_off[s], wk.cap = a.out_cap[s];
-        wk.W = W, wk.mask = mask, wk.wbits = a.wbits, wk.lbits = a.lbits, wk.minp = minp, wk.ext = ext;
-        wk.n = n, wk.p0 = 0, wk.wp_e = 0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0, wk.blk = a.blk;
-        wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0;
-        wk.acc = 0, wk.nacc = 0, wk.opos = 0, wk.gpos = 0, wk.tbits = 0, wk.lane = lane;
-        wk.put(a.header, 8);  // compressor.c:236-241
-        if (a.dict_reset) wk.put(0, 8);
+        wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
+        wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
+        wk.wp_e = 0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
+        wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+        uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
-        uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters, uniform over the workgroup
+        // workgroup-uniform output state
+        uint32_t carry = a.dict_reset ? 16u : 8u;  // bits already sitting in obuf (header; a second byte is zero)
+        uint32_t gpos = 0;                         // bytes already flushed to HBM
+        uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters
+        bool need_match = true;
 #ifdef TAMP_PROF
         unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long pc = __builtin_readcyclecounter();
-#define TAMP_PROF_MARK(i) do { __syncthreads(); unsigned long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } while (0)
-#else
-#define TAMP_PROF_MARK(i) do { } while (0)
 #endif
         for (;;) {
-            // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
             const uint32_t left = n - e_p0;
-            const uint32_t room = a.blk + kRing + kPendMax;
-            const uint32_t nload = left < room ? left : room;
             const uint32_t nvalid = left < a.blk ? left : a.blk;
-            {
-                const uint8_t* src = in + e_p0;
-                const uint32_t nfill = align_up(nload + 16, 4);  // zero tail so stray look-ahead reads are defined
-                if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
-                    const uint32_t nw = nload >> 2;
-                    for (uint32_t k = tid; k < nw; k += nt)
-                        reinterpret_cast<uint32_t*>(ebuf + W)[k] = reinterpret_cast<const uint32_t*>(src)[k];
-                    for (uint32_t k = (nw << 2) + tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
-                } else {
-                    for (uint32_t k = tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
-                }
-            }
-            for (uint32_t k = tid; k < kHashBuckets; k += nt) cnt[k] = 0;
-            __syncthreads();
-            TAMP_PROF_MARK(0);
-
-            // ---------------- index: counting sort of buffer positions by bigram hash ----------------
-            // positions c in [0, NE): every candidate any query of this block may need
-            const uint32_t NE = nvalid >= 1 ? W + nvalid - 2 : 0;
-            for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
-                const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
-                const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    if (c4 + j < NE) {
-                        const uint32_t pair = __builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu;
-                        atomicAdd(&cnt[bigram_hash(pair)], 1u);
+            if (need_match) {
+                // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
+                const uint32_t room = a.blk + kRing + kPendMax;
+                const uint32_t nload = left < room ? left : room;
+                {
+                    const uint8_t* src = in + e_p0;
+                    const uint32_t nfill = align_up(nload + 20, 4);  // zero tail: stray look-ahead reads are defined
+                    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+                        const uint32_t nw = nload >> 2;
+                        for (uint32_t k = tid; k < nw; k += nt)
+                            reinterpret_cast<uint32_t*>(ebuf + W)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+                        for (uint32_t k = (nw << 2) + tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
+                    } else {
+                        for (uint32_t k = tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
                     }
                 }
-            }
-            __syncthreads();
-            {  // exclusive scan of cnt[0..HB) in place
-                const uint32_t per = kHashBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
-                uint32_t sum = 0;
-                for (uint32_t k = 0; k < per; k++) sum += cnt[tid * per + k];
-                uint32_t incl = sum;
-#pragma unroll
-                for (int off = 1; off < kWave; off <<= 1) {
-                    uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                    if (lane >= off) incl += o;
-                }
-                if (lane == kWave - 1) ctl[8 + wave] = incl;
+                for (uint32_t k = tid; k < kHashBuckets / 2; k += nt) cntw[k] = 0;
+                for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a.blk + 128; k += nt) blen[k] = 0x80;  // sentinels
                 __syncthreads();
-                uint32_t base = 0;
-                for (uint32_t w2 = 0; w2 < wave; w2++) base += ctl[8 + w2];
-                uint32_t run = base + incl - sum;
-                for (uint32_t k = 0; k < per; k++) {
-                    uint32_t v = cnt[tid * per + k];
-                    cnt[tid * per + k] = run;
-                    run += v;
-                }
-            }
-            __syncthreads();
-            for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
-                const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
-                const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    if (c4 + j < NE) {
-                        const uint32_t pair = __builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu;
-                        const uint32_t slot = atomicAdd(&cnt[bigram_hash(pair)], 1u);
-                        ent[slot] = (uint16_t)(c4 + j);
-                    }
-                }
-            }
-            __syncthreads();
-            TAMP_PROF_MARK(1);
-            // now bucket h = ent[(h ? cnt[h-1] : 0) .. cnt[h])
+                TAMP_PROF_MARK(0);
 
-            // ---------------- match phase: find_best_match for every position of the block ----------------
-            for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
-                const uint32_t leftq = n - (e_p0 + q);
-                const uint32_t R = leftq < kRing ? leftq : kRing;
-                uint32_t key = 0;
-                if (R >= minp) {
-                    const uint32_t cap = R < maxp ? R : maxp;
-                    uint32_t P[4];
+                // ---------------- index: counting sort of buffer positions by bigram ----------------
+                const uint32_t NE = nvalid ? W + nvalid : 0;  // positions 0..NE-1 (every query's own bigram included)
+                for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
+                    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
+                    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = lds_u32_unaligned(ebuf, W + q + 4 * j);
-                    const uint32_t h = bigram_hash(P[0] & 0xFFFFu);
-                    const uint32_t s0 = h ? cnt[h - 1] : 0, s1 = cnt[h];
-                    const uint32_t chi = q + W - 2;  // last candidate served by the index
-                    for (uint32_t sl = s0; sl < s1; sl++) {
-                        const uint32_t c = ent[sl];
-                        if (c < q || c > chi) continue;
-                        const uint32_t i = (e_wp + c) & mask;  // window index of the candidate
-                        if (i == mask) continue;               // index W-1 cannot start a match
-                        const uint32_t lim = min(cap, W - i);  // may not run past index W-1
-                        uint32_t len;
-                        if (c + 16 <= q + W)
-                            len = min(prefix_len16(ebuf, c, P), lim);
-                        else
-                            len = prefix_len_wrapped(ebuf, c, q, W, lim);
-                        const uint32_t k = (len << 16) | (0xFFFFu - i);
-                        if (len >= 2 && k > key) key = k;
-                    }
-                    {  // the newest window byte pairs with the OLDEST one: not in the index
-                        const uint32_t c = q + W - 1;
-                        const uint32_t i = (e_wp + c) & mask;
-                        if (i != mask) {
-                            const uint32_t len = prefix_len_wrapped(ebuf, c, q, W, min(cap, W - i));
-                            const uint32_t k = (len << 16) | (0xFFFFu - i);
-                            if (len >= 2 && k > key) key = k;
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (c4 + j < NE) {
+                            const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRemBits;
+                            atomicAdd(&cntw[h >> 1], 1u << ((h & 1) * 16));
                         }
                     }
                 }
-                blen[q] = (uint8_t)(key >> 16);
-                bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
+                __syncthreads();
+                {  // exclusive scan of the 2048 u16 counters in place
+                    const uint32_t per = kHashBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
+                    uint32_t sum = 0;
+                    for (uint32_t k = 0; k < per; k++) sum += cnt16[tid * per + k];
+                    uint32_t incl = sum;
+#pragma unroll
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                        if (lane >= off) incl += o;
+                    }
+                    if (lane == kWave - 1) ctl[cWave + wave] = incl;
+                    __syncthreads();
+                    uint32_t run = incl - sum;
+                    for (uint32_t w2 = 0; w2 < wave; w2++) run += ctl[cWave + w2];
+                    for (uint32_t k = 0; k < per; k++) {
+                        uint32_t v = cnt16[tid * per + k];
+                        cnt16[tid * per + k] = (uint16_t)run;
+                        run += v;
+                    }
+                }
+                __syncthreads();
+                // tile-ordered scatter: after tile t every bucket lists the positions of tiles 0..t in tile order,
+                // and the cursor read back after the tile is where a query of that tile starts scanning downwards
+                for (uint32_t t0 = 0; t0 < NE; t0 += nt) {
+                    const uint32_t c = t0 + tid;
+                    uint32_t h = 0;
+                    if (c < NE) {
+                        const uint32_t b4 = lds_u32_unaligned(ebuf, c);
+                        const uint32_t mx = mix16(b4 & 0xFFFFu);
+                        h = mx >> kRemBits;
+                        const uint32_t sh = (h & 1) * 16;
+                        const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
+                        if (PACKED)
+                            ent[(old >> sh) & 0xFFFFu] = c | entry_payload(b4, mx);
+                        else
+                            ent16[(old >> sh) & 0xFFFFu] = (uint16_t)c;
+                    }
+                    __syncthreads();
+                    if (c < NE && c >= W) bidx[c - W] = cnt16[h];
+                    __syncthreads();
+                }
+                TAMP_PROF_MARK(1);
+
+                // ---------------- match: find_best_match for every position of the block ----------------
+                for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
+                    const uint32_t leftq = n - (e_p0 + q);
+                    const uint32_t R = leftq < kRing ? leftq : kRing;
+                    uint32_t key = 0;
+                    uint32_t P[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) P[j] = lds_u32_unaligned(ebuf, W + q + 4 * j);
+                    if (R >= minp) {
+                        const uint32_t cap_len = R < maxp ? R : maxp;
+                        const uint32_t mx = mix16(P[0] & 0xFFFFu);
+                        const uint32_t h = mx >> kRemBits;
+                        const uint32_t pk = entry_payload(P[0], mx);
+                        const int32_t s_lo = h ? (int32_t)cnt16[h - 1] : 0;  // bucket start (= final cursor of h-1)
+                        const uint32_t chi = q + W - 2;                      // newest candidate served by the index
+                        const uint32_t ctile = (q / nt) * nt;                // buckets are ordered by tile of c
+                        for (int32_t sl = (int32_t)bidx[q] - 1; sl >= s_lo; sl--) {
+                            const uint32_t e = PACKED ? ent[sl] : (uint32_t)ent16[sl];
+                            const uint32_t c = e & 0xFFFFu;
+                            if (c < ctile) break;  // every older entry has left the window
+                            if (c > chi || c < q) continue;
+                            // position-only entries: classify as "deep" and let the byte compare decide
+                            const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
+                            if (x & ((1u << kRemBits) - 1)) continue;  // different bigram sharing the bucket
+                            const uint32_t i = (e_wp + c) & mask;      // window index of the candidate
+                            if (i == mask) continue;                   // index W-1 cannot start a match
+                            const uint32_t lim = min(cap_len, W - i);  // may not run past index W-1
+                            uint32_t len;
+                            if (c + 16 > q + W)
+                                len = prefix_len_wrapped(ebuf, c, q, W, lim);
+                            else if (x & (0xFFu << kRemBits))
+                                len = 2;
+                            else if (x >> (8 + kRemBits))
+                                len = min(3u, lim);
+                            else
+                                len = min(prefix_len16(ebuf, c, P), lim);
+                            const uint32_t k = (len << 16) | (0xFFFFu - i);
+                            if (len >= 2 && k > key) key = k;
+                        }
+                        {  // the newest window byte pairs with the OLDEST one: not in the index
+                            const uint32_t c = q + W - 1;
+                            const uint32_t i = (e_wp + c) & mask;
+                            if (i != mask && ebuf[c] == (P[0] & 0xFFu)) {
+                                const uint32_t len = prefix_len_wrapped(ebuf, c, q, W, min(cap_len, W - i));
+                                const uint32_t k = (len << 16) | (0xFFFFu - i);
+                                if (len >= 2 && k > key) key = k;
+                            }
+                        }
+                    }
+                    const uint32_t len = key >> 16;
+                    // positions where poll_extended_handling does more than fall through (compressor.c:470-503)
+                    bool slow = false;
+                    if (ext) {
+                        const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
+                        slow = (prev == b0 && (b1 == b0 || R == 1)) || len > minp + 11;
+                    }
+                    blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
+                    bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
+                }
+                __syncthreads();
+                TAMP_PROF_MARK(2);
             }
-            __syncthreads();
-            TAMP_PROF_MARK(2);
 
             // ---------------- walk: wave 0 ----------------
             if (wave == 0) {
                 wk.nvalid = nvalid;
-                uint32_t done = 0, result = 0, total_bytes = 0;
+                wk.ntok = 0, wk.ns = 0;
+                uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
                 for (;;) {
-                    const uint32_t p = wk.p0 + wk.rd;
+                    if (wk.ntok + 72 > L.tokcap || wk.ns + 8 > kSlowCap) {
+                        act = kActContinue;
+                        break;
+                    }
+                    const bool clean = wk.wr == wk.rd && wk.rle_count == 0 && wk.ext_count == 0;
+                    if (clean && wk.rd < nvalid) {
+                        // plain steps, 64 positions per register: one v_readlane per token
+                        const uint32_t rdu = Walk::uni(wk.rd);
+                        const uint32_t b = rdu & ~63u;
+                        const uint32_t v = blen[b + lane];
+                        uint32_t pos = rdu - b;
+                        uint32_t mlo = 0, mhi = 0;
+                        while (pos < 64) {
+                            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)pos);
+                            if (sv & 0x80u) break;
+                            if (pos < 32)
+                                mlo |= 1u << pos;
+                            else
+                                mhi |= 1u << (pos - 32);
+                            pos += sv >= minp ? sv : 1u;
+                        }
+                        if (mlo | mhi) {
+                            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
+                            const uint32_t mine = lane < 32 ? (mlo >> lane) & 1u : (mhi >> (lane - 32)) & 1u;
+                            if (mine) toklist[wk.ntok + below] = (uint16_t)(b + lane);
+                            wk.ntok += (uint32_t)(__builtin_popcount(mlo) + __builtin_popcount(mhi));
+                        }
+                        wk.rd = wk.wr = b + pos;
+                        if (pos >= 64) continue;
+                    }
+                    const uint32_t p = w_p0 + wk.rd;
                     if (p < n) {
                         const uint32_t pending = wk.rle_count + wk.ext_count;
                         int r = Walk::kStepRebase;
-                        if (wk.rd <= wk.blk + pending) {
+                        if (wk.rd <= a.blk + pending) {
                             const uint32_t leftp = n - p;
                             r = wk.step(leftp < kRing ? leftp : kRing);
                         }
-                        if (r == Walk::kStepRebase) break;
+                        if (r == Walk::kStepRebase) {
+                            act = kActRebase;
+                            break;
+                        }
                         if (r == Walk::kStepExcess) {
-                            total_bytes = wk.tbits >> 3;  // whole bytes emitted before the offending literal
-                            wk.drain_whole_bytes();
-                            result = (uint32_t)(int32_t)kExcessBits;
-                            done = 1;
+                            excess_tok = wk.ntok;
+                            act = kActDone;
                             break;
                         }
                     } else if (ext && wk.rle_count >= 1) {  // compressor.c:748-763
                         if (wk.rle_count == 1) {
-                            const uint32_t c = wk.win((wk.wp() - 1) & mask);
-                            wk.put((1u << a.lbits) | c, a.lbits + 1u);
+                            const uint32_t c = wk.win((wk.wp() - 1) & mask);  // uniform (readfirstlane inside)
+                            wk.put((1u << lbits) | c, lbits + 1u);
                             wk.append(1, wk.wr + 1 == wk.rd, [&](uint32_t) { return c; });
                         } else {
                             wk.emit_rle(wk.rle_count);
@@ -540,62 +634,178 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     } else if (ext && wk.ext_count) {  // compressor.c:764-766
                         wk.emit_ext();
                     } else {
-                        if (wk.nacc & 7) wk.put(0, 8 - (wk.nacc & 7));  // compressor.c:799-807
-                        total_bytes = wk.tbits >> 3;
-                        wk.drain_whole_bytes();
-                        result = (uint32_t)(int32_t)kOk;
-                        done = 1;
+                        act = kActDone;
                         break;
                     }
                 }
-                if (done) {
-                    if (total_bytes > wk.cap) {
-                        result = (uint32_t)(int32_t)kOutputFull;
-                        total_bytes = wk.cap;
-                    }
-                    if (lane == 0) {
-                        a.out_len[s] = total_bytes;
-                        a.status[s] = (int8_t)(int32_t)result;
-                    }
-                } else {
-                    // re-base request: drop the lag, keep bytes a pending RLE run / extended match has
-                    // consumed but not written (oracle/tamp_model.c m_epoch_begin)
+                if (act == kActRebase) {
+                    // drop the lag, keep the bytes a pending RLE run / extended match has consumed but not
+                    // written (oracle/tamp_model.c m_epoch_begin)
                     const uint32_t pending = wk.rle_count + wk.ext_count;
                     const uint32_t shift = wk.wr;
                     wk.wp_e = wk.wp();
-                    wk.p0 += wk.rd - pending;
+                    w_p0 += wk.rd - pending;
                     wk.wr = 0;
                     wk.rd = pending;
                     if (lane == 0) {
-                        ctl[1] = shift;
-                        ctl[2] = wk.p0;
-                        ctl[3] = pending;
-                        ctl[4] = wk.wp_e;
+                        ctl[cShift] = shift;
+                        ctl[cP0] = w_p0;
+                        ctl[cPending] = pending;
+                        ctl[cWp] = wk.wp_e;
                     }
                 }
-                if (lane == 0) ctl[0] = done;
+                if (lane == 0) {
+                    ctl[cAct] = act;
+                    ctl[cNtok] = wk.ntok;
+                    ctl[cExcess] = excess_tok;
+                }
             }
             __syncthreads();
             TAMP_PROF_MARK(3);
-            if (ctl[0]) break;
-            const uint32_t shift = ctl[1];
-            e_p0 = ctl[2];
-            e_pending = ctl[3];
-            e_wp = ctl[4];
-            // ---------------- re-base: ebuf[0..W) <- ebuf[shift..shift+W) (moving left, chunked) ----------------
-            if (shift) {
-                for (uint32_t base = 0; base < W; base += nt * 4) {
-                    const uint32_t k = base + tid * 4;
-                    uint32_t v = 0;
-                    if (k < W) v = lds_u32_unaligned(ebuf, shift + k);
-                    __syncthreads();
-                    if (k < W) *reinterpret_cast<uint32_t*>(ebuf + k) = v;
-                    __syncthreads();
+
+            // ---------------- emit: token list -> bits (all threads) ----------------
+            uint32_t act = ctl[cAct];
+            const uint32_t ntok = ctl[cNtok];
+            const uint32_t K = (ntok + nt - 1) / nt;
+            const uint32_t k0 = min(tid * K, ntok), k1 = min(k0 + K, ntok);
+            auto token = [&](uint32_t k, uint32_t& v, uint32_t& nb) -> bool {  // false: literal with excess bits
+                const uint32_t e = toklist[k];
+                if (e & 0x8000u) {
+                    v = stok[2 * (e & 0x7FFFu)];
+                    nb = stok[2 * (e & 0x7FFFu) + 1];
+                    return true;
+                }
+                const uint32_t len = blen[e] & 0x1Fu;
+                if (len < minp) {  // compressor.c:625-632
+                    const uint32_t c = ebuf[W + e];
+                    v = (1u << lbits) | c;
+                    nb = lbits + 1;
+                    return (c >> lbits) == 0;
+                }
+                v = (tok_code(len - minp) << wbits) | bidx[e];  // compressor.c:646-649
+                nb = tok_nbits(len - minp) + wbits;
+                return true;
+            };
+            if (lbits < 8) {  // TAMP_EXCESS_BITS: the stream ends at the first literal that does not fit
+                uint32_t v, nb;
+                for (uint32_t k = k0; k < k1; k++)
+                    if (!token(k, v, nb)) {
+                        atomicMin(const_cast<uint32_t*>(&ctl[cExcess]), k);
+                        break;
+                    }
+                __syncthreads();
+            }
+            const uint32_t limit = min((uint32_t)ctl[cExcess], ntok);
+            const bool excess = ctl[cExcess] != 0xFFFFFFFFu;
+            uint32_t mybits = 0;
+            for (uint32_t k = k0; k < k1 && k < limit; k++) {
+                uint32_t v, nb;
+                token(k, v, nb);
+                mybits += nb;
+            }
+            uint32_t incl = mybits;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                uint32_t o2 = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += o2;
+            }
+            if (lane == kWave - 1) ctl[cWave + wave] = incl;
+            __syncthreads();
+            uint32_t o = carry + incl - mybits, segbits = 0;
+            for (uint32_t w2 = 0; w2 < (nt >> 6); w2++) {
+                const uint32_t wt = ctl[cWave + w2];
+                if (w2 < wave) o += wt;
+                segbits += wt;
+            }
+            {  // MSb-first scatter of this thread's contiguous run of tokens
+                uint32_t wi = o >> 5, ph = o & 31, fill = 0;
+                uint64_t acc = 0;
+                for (uint32_t k = k0; k < k1 && k < limit; k++) {
+                    uint32_t v, nb;
+                    token(k, v, nb);
+                    acc = (acc << nb) | v;
+                    fill += nb;
+                    while (ph + fill >= 32) {
+                        const uint32_t take = 32 - ph;
+                        uint32_t w = (uint32_t)(acc >> (fill - take));
+                        if (take < 32) w &= (1u << take) - 1;
+                        if (ph == 0)
+                            obuf[wi] = __builtin_bswap32(w);
+                        else
+                            atomicOr(&obuf[wi], __builtin_bswap32(w));
+                        fill -= take;
+                        ph = 0;
+                        wi++;
+                    }
+                }
+                if (fill) {
+                    const uint32_t w = ((uint32_t)acc & ((1u << fill) - 1)) << (32 - ph - fill);
+                    atomicOr(&obuf[wi], __builtin_bswap32(w));
                 }
             }
+            __syncthreads();
+            const uint32_t tot = carry + segbits;  // bits now in obuf
+            if (excess) act = kActDone;
+            // flush whole words (or, at the end, the zero-padded / truncated byte count) to HBM
+            uint32_t nbytes;
+            if (act == kActDone)
+                nbytes = excess ? (tot >> 3) : ((tot + 7) >> 3);  // compressor.c:629-631 / :799-807
+            else
+                nbytes = (tot >> 5) << 2;
+            {
+                const uint8_t* ob = reinterpret_cast<const uint8_t*>(obuf);
+                uint8_t* dst = gout + gpos;
+                const uint32_t room2 = gpos < cap ? cap - gpos : 0;
+                const uint32_t nw = nbytes < room2 ? nbytes : room2;
+                if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+                    for (uint32_t k = tid; k < (nw >> 2); k += nt) reinterpret_cast<uint32_t*>(dst)[k] = obuf[k];
+                    for (uint32_t k = (nw & ~3u) + tid; k < nw; k += nt) dst[k] = ob[k];
+                } else {
+                    for (uint32_t k = tid; k < nw; k += nt) dst[k] = ob[k];
+                }
+            }
+            if (act == kActDone) {
+                if (tid == 0) {
+                    const uint32_t total_bytes = gpos + nbytes;
+                    a.out_len[s] = total_bytes < cap ? total_bytes : cap;
+                    a.status[s] = total_bytes > cap ? kOutputFull : (excess ? kExcessBits : kOk);
+                }
+                break;
+            }
+            __syncthreads();
+            {  // keep the partial last word, clear the rest for the next segment
+                const uint32_t nfull = tot >> 5;
+                const uint32_t lastw = obuf[nfull];
+                const uint32_t used = ((tot + 31) >> 5) + 1;
+                __syncthreads();
+                for (uint32_t k = tid; k < used && k < L.obuf_words; k += nt) obuf[k] = k == 0 ? lastw : 0;
+                gpos += nbytes;
+                carry = tot & 31;
+            }
+            TAMP_PROF_MARK(4);
+            need_match = act == kActRebase;
+            if (act == kActRebase) {
+                const uint32_t shift = ctl[cShift];
+                e_p0 = ctl[cP0];
+                e_pending = ctl[cPending];
+                e_wp = ctl[cWp];
+                // re-base: ebuf[0..W) <- ebuf[shift..shift+W) (moving left, chunked)
+                if (shift) {
+                    for (uint32_t base = 0; base < W; base += nt * 4) {
+                        const uint32_t k = base + tid * 4;
+                        uint32_t v = 0;
+                        if (k < W) v = lds_u32_unaligned(ebuf, shift + k);
+                        __syncthreads();
+                        if (k < W) *reinterpret_cast<uint32_t*>(ebuf + k) = v;
+                        __syncthreads();
+                    }
+                }
+            }
+            __syncthreads();
         }
 #ifdef TAMP_PROF
-        if (tid == 0 && a.prof) for (int i = 0; i < 6; i++) atomicAdd(&a.prof[i], pt[i]);
+        if (tid == 0 && a.prof)
+            for (int i = 0; i < 6; i++) atomicAdd(&a.prof[i], pt[i]);
 #endif
         __syncthreads();  // ctl / LDS reuse by the next stream
     }
