@@ -54,29 +54,35 @@ struct CompressArgs {
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
     uint32_t ebuf, cnt, ent, blen, bidx, obuf, ctl, total;
-    uint32_t tokcap, obuf_words;
+    uint32_t tokcap, obuf_words, jump, count;  // jump/count: byte offsets of the walk's tables inside `ent`
     __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed) {
-        uint32_t o = 0;
+        uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
         cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
         o += kHashBuckets * 2;
         tokcap = blk + kPendMax + kRing + 80;
+        jump = align_up(tokcap * 2, 16);
+        count = jump + blk * 2;
         ent = o;  // (W + blk) index entries (u32 packed, or u16 position-only for the largest windows);
                   // the walk reuses the space for the token list (tokcap x u16)
         {
-            const uint32_t index_bytes = (W + blk + 16) * (packed ? 4u : 2u), list_bytes = tokcap * 2;
-            o += align_up(index_bytes > list_bytes ? index_bytes : list_bytes, 16);
+            // after the match phase the same space holds the token list (tokcap x u16) and the per-position
+            // jump tables of the walk: jump target (u16) and token count (u8)
+            const uint32_t index_bytes = (W + blk + 16) * (packed ? 4u : 2u);
+            const uint32_t walk_bytes = align_up(tokcap * 2, 16) + blk * 2 + blk + 16;
+            o += align_up(index_bytes > walk_bytes ? index_bytes : walk_bytes, 16);
         }
         blen = o;
         o += align_up(blk + 128, 16);
         bidx = o;
         o += align_up(blk * 2, 16);
         obuf_words = ((blk + kPendMax + kRing + 64) * 9 + kSlowCap * 25) / 32 + 8;
+        if (obuf_words < 4 + blk / 2) obuf_words = 4 + blk / 2;  // words 4.. hold the u16 scan starts during match
         obuf = o;
         o += align_up(obuf_words * 4, 16);
         ctl = o;
-        o += 64;
+        o += 64 + 64 * 4;  // control words + 64 sort bins
         total = o;
     }
 };
@@ -131,17 +137,27 @@ __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c
     return 16;
 }
 
-// Candidate whose bytes may run past the newest window byte (the ring continues with the oldest).
-__device__ __forceinline__ uint32_t prefix_len_wrapped(const uint8_t* ebuf, uint32_t c, uint32_t q, uint32_t W,
-                                                       uint32_t lim) {
-    uint32_t len = 0;
-    while (len < lim) {
-        uint32_t s = c + len;
-        if (s >= q + W) s -= W;
-        if (ebuf[s] != ebuf[W + q + len]) break;
-        len++;
+// Candidate whose bytes run past the newest window byte: the ring continues with the OLDEST window byte, i.e.
+// candidate byte k is ebuf[c + k] for k < t and ebuf[c - W + k] for k >= t, with t = q + W - c in 1..15.
+// Both halves are fetched as 16 unaligned bytes and blended; returns the common prefix length with P (0..16).
+__device__ __forceinline__ uint32_t prefix_len_wrapped16(const uint8_t* ebuf, uint32_t c, uint32_t t, uint32_t W,
+                                                         const uint32_t (&P)[4]) {
+    const uint32_t* wa = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
+    const uint32_t sa = c & 3u;
+    const int32_t ob = (int32_t)c - (int32_t)W;  // >= -15: the slack in front of ebuf keeps this inside LDS
+    const uint32_t* wb = reinterpret_cast<const uint32_t*>(ebuf + (ob & ~3));
+    const uint32_t sb = (uint32_t)ob & 3u;
+    uint32_t res = 16;
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        const uint32_t xa = __builtin_amdgcn_alignbyte(wa[j + 1], wa[j], sa);
+        const uint32_t xb = __builtin_amdgcn_alignbyte(wb[j + 1], wb[j], sb);
+        const uint32_t lo = 4u * (uint32_t)j;  // bytes lo..lo+3 of the candidate
+        const uint32_t m = t >= lo + 4 ? 0xFFFFFFFFu : (t <= lo ? 0u : (1u << (8 * (t - lo))) - 1u);
+        const uint32_t x = ((xa & m) | (xb & ~m)) ^ P[j];
+        if (x) res = lo + ((uint32_t)__builtin_ctz(x) >> 3);
     }
-    return len;
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,11 +394,18 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
     uint32_t* const ent = reinterpret_cast<uint32_t*>(smem + L.ent);
     uint16_t* const ent16 = reinterpret_cast<uint16_t*>(smem + L.ent);
     uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
+    uint16_t* const jump16 = reinterpret_cast<uint16_t*>(smem + L.ent + L.jump);   // alias, same reason
+    uint8_t* const count8 = smem + L.ent + L.count;                                 // alias, same reason
+    uint16_t* const segpos = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048);      // alias: walk scratch
+    uint16_t* const segbase = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048 + 256);
     uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
     uint8_t* const blen = smem + L.blen;
     uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
     uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
+    uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
+    uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
     volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
+    uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 64);
 
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1);
@@ -484,8 +507,14 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     }
                 }
                 __syncthreads();
-                // tile-ordered scatter: after tile t every bucket lists the positions of tiles 0..t in tile order,
-                // and the cursor read back after the tile is where a query of that tile starts scanning downwards
+                // Tile-ordered scatter.  After tile t every bucket lists the positions of tiles 0..t in tile order.
+                // Two cursor snapshots bracket what a query must scan: the cursor of its bucket when the tile holding
+                // its oldest window byte starts (qstart) and after the tile holding its own position (top, in bidx).
+                if (tid < nvalid) {
+                    const uint32_t b4 = lds_u32_unaligned(ebuf, W + tid);
+                    qstart[tid] = cnt16[mix16(b4 & 0xFFFFu) >> kRemBits];  // queries of tile 0: bucket start
+                }
+                __syncthreads();
                 for (uint32_t t0 = 0; t0 < NE; t0 += nt) {
                     const uint32_t c = t0 + tid;
                     uint32_t h = 0;
@@ -502,54 +531,77 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     }
                     __syncthreads();
                     if (c < NE && c >= W) bidx[c - W] = cnt16[h];
+                    const uint32_t q2 = t0 + nt + tid;  // queries whose oldest window byte lies in the next tile
+                    if (q2 < nvalid) {
+                        const uint32_t b4 = lds_u32_unaligned(ebuf, W + q2);
+                        qstart[q2] = cnt16[mix16(b4 & 0xFFFFu) >> kRemBits];
+                    }
                     __syncthreads();
                 }
+                // Order the queries by scan length (counting sort, longest first) so that the 64 lanes of a wave
+                // loop about equally often: the greedy per-lane scan is otherwise paced by its longest bucket.
+                if (tid < 64) bins[tid] = 0;
+                __syncthreads();
+                for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
+                    const uint32_t Lq = min((uint32_t)bidx[q] - (uint32_t)qstart[q], 63u);
+                    atomicAdd(&bins[63 - Lq], 1u);
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const uint32_t v = bins[lane];
+                    uint32_t incl = v;
+#pragma unroll
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        uint32_t o2 = (uint32_t)__shfl_up((int)incl, off);
+                        if (lane >= off) incl += o2;
+                    }
+                    bins[lane] = incl - v;
+                }
+                __syncthreads();
+                for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
+                    const uint32_t Lq = min((uint32_t)bidx[q] - (uint32_t)qstart[q], 63u);
+                    sorted[atomicAdd(&bins[63 - Lq], 1u)] = (uint16_t)q;
+                }
+                __syncthreads();
                 TAMP_PROF_MARK(1);
 
                 // ---------------- match: find_best_match for every position of the block ----------------
-                for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
+                const uint32_t nq = nvalid - e_pending;
+                for (uint32_t j = tid; j < nq; j += nt) {
+                    const uint32_t q = sorted[j];
                     const uint32_t leftq = n - (e_p0 + q);
                     const uint32_t R = leftq < kRing ? leftq : kRing;
                     uint32_t key = 0;
                     uint32_t P[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = lds_u32_unaligned(ebuf, W + q + 4 * j);
+                    for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
                     if (R >= minp) {
                         const uint32_t cap_len = R < maxp ? R : maxp;
-                        const uint32_t mx = mix16(P[0] & 0xFFFFu);
-                        const uint32_t h = mx >> kRemBits;
-                        const uint32_t pk = entry_payload(P[0], mx);
-                        const int32_t s_lo = h ? (int32_t)cnt16[h - 1] : 0;  // bucket start (= final cursor of h-1)
-                        const uint32_t chi = q + W - 2;                      // newest candidate served by the index
-                        const uint32_t ctile = (q / nt) * nt;                // buckets are ordered by tile of c
-                        for (int32_t sl = (int32_t)bidx[q] - 1; sl >= s_lo; sl--) {
+                        const uint32_t pk = entry_payload(P[0], mix16(P[0] & 0xFFFFu));
+                        const uint32_t chi = q + W - 2;  // newest candidate served by the index
+                        const uint32_t s_hi = bidx[q];
+                        for (uint32_t sl = qstart[q]; sl < s_hi; sl++) {
                             const uint32_t e = PACKED ? ent[sl] : (uint32_t)ent16[sl];
                             const uint32_t c = e & 0xFFFFu;
-                            if (c < ctile) break;  // every older entry has left the window
-                            if (c > chi || c < q) continue;
-                            // position-only entries: classify as "deep" and let the byte compare decide
+                            // position-only entries: everything is "deep", the byte compare decides
                             const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
-                            if (x & ((1u << kRemBits) - 1)) continue;  // different bigram sharing the bucket
-                            const uint32_t i = (e_wp + c) & mask;      // window index of the candidate
-                            if (i == mask) continue;                   // index W-1 cannot start a match
+                            const uint32_t i = (e_wp + c) & mask;  // window index of the candidate
+                            // in the window, same bigram, and not index W-1 (which cannot start a match)
+                            const bool ok = c >= q && c <= chi && (x & ((1u << kRemBits) - 1)) == 0 && i != mask;
                             const uint32_t lim = min(cap_len, W - i);  // may not run past index W-1
-                            uint32_t len;
-                            if (c + 16 > q + W)
-                                len = prefix_len_wrapped(ebuf, c, q, W, lim);
-                            else if (x & (0xFFu << kRemBits))
-                                len = 2;
-                            else if (x >> (8 + kRemBits))
-                                len = min(3u, lim);
-                            else
-                                len = min(prefix_len16(ebuf, c, P), lim);
+                            const bool wraps = c + 16 > q + W;
+                            uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
+                            if (ok && (wraps || (x >> kRemBits) == 0))  // next two bytes agree too: compare for real
+                                len = wraps ? prefix_len_wrapped16(ebuf, c, q + W - c, W, P) : prefix_len16(ebuf, c, P);
+                            len = min(len, lim);
                             const uint32_t k = (len << 16) | (0xFFFFu - i);
-                            if (len >= 2 && k > key) key = k;
+                            if (ok && len >= 2 && k > key) key = k;
                         }
                         {  // the newest window byte pairs with the OLDEST one: not in the index
                             const uint32_t c = q + W - 1;
                             const uint32_t i = (e_wp + c) & mask;
                             if (i != mask && ebuf[c] == (P[0] & 0xFFu)) {
-                                const uint32_t len = prefix_len_wrapped(ebuf, c, q, W, min(cap_len, W - i));
+                                const uint32_t len = min(prefix_len_wrapped16(ebuf, c, 1, W, P), min(cap_len, W - i));
                                 const uint32_t k = (len << 16) | (0xFFFFu - i);
                                 if (len >= 2 && k > key) key = k;
                             }
@@ -564,6 +616,30 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     }
                     blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
                     bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
+                }
+                __syncthreads();
+                for (uint32_t k = 4 + tid; k < 4 + a.blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
+                // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
+                // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
+                // the chain of plain steps starting there leaves the block (or the "slow" position it stops at) and how
+                // many tokens it emits on the way.
+                for (uint32_t b = wave * 64; b < nvalid; b += (nt >> 6) * 64) {
+                    const uint32_t sv = blen[b + lane];  // sentinels (0x80) beyond nvalid
+                    const bool slowp = (sv & 0x80u) != 0;
+                    const uint32_t stepv = sv >= minp ? (sv & 0x1Fu) : 1u;
+                    // packed: target (relative, 0..79) | count << 8 | finished << 16
+                    uint32_t st = slowp ? ((uint32_t)lane | (1u << 16)) : (((uint32_t)lane + stepv) | (1u << 8));
+                    if ((st & 0xFFu) >= 64u) st |= 1u << 16;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        const uint32_t tgt = (st >> 16) ? (uint32_t)lane : (st & 0xFFu);
+                        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tgt << 2), (int)st);
+                        if (!(st >> 16)) st = (o2 & 0x100FFu) | (((st >> 8) & 0xFFu) + ((o2 >> 8) & 0xFFu)) << 8;
+                    }
+                    if (b + lane < nvalid) {
+                        jump16[b + lane] = (uint16_t)(b + (st & 0xFFu));
+                        count8[b + lane] = (uint8_t)((st >> 8) & 0xFFu);
+                    }
                 }
                 __syncthreads();
                 TAMP_PROF_MARK(2);
@@ -581,29 +657,34 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     }
                     const bool clean = wk.wr == wk.rd && wk.rle_count == 0 && wk.ext_count == 0;
                     if (clean && wk.rd < nvalid) {
-                        // plain steps, 64 positions per register: one v_readlane per token
-                        const uint32_t rdu = Walk::uni(wk.rd);
-                        const uint32_t b = rdu & ~63u;
-                        const uint32_t v = blen[b + lane];
-                        uint32_t pos = rdu - b;
-                        uint32_t mlo = 0, mhi = 0;
-                        while (pos < 64) {
-                            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)pos);
-                            if (sv & 0x80u) break;
-                            if (pos < 32)
-                                mlo |= 1u << pos;
-                            else
-                                mhi |= 1u << (pos - 32);
-                            pos += sv >= minp ? sv : 1u;
+                        // Plain steps: hop from block to block through the jump tables (one dependent LDS read per 64
+                        // positions), then let one lane per block list that block's token positions.
+                        uint32_t pos = Walk::uni(wk.rd), total = 0, nseg = 0;
+                        while (pos < nvalid && nseg < 64 && wk.ntok + total + 64 <= L.tokcap) {
+                            const uint32_t j = Walk::uni(jump16[pos]);
+                            if (j == pos) break;  // a position the state machine has to look at
+                            const uint32_t cpos = Walk::uni(count8[pos]);
+                            if (lane == 0) {
+                                segpos[nseg] = (uint16_t)pos;
+                                segbase[nseg] = (uint16_t)total;
+                            }
+                            nseg++;
+                            total += cpos;
+                            pos = j;
                         }
-                        if (mlo | mhi) {
-                            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
-                            const uint32_t mine = lane < 32 ? (mlo >> lane) & 1u : (mhi >> (lane - 32)) & 1u;
-                            if (mine) toklist[wk.ntok + below] = (uint16_t)(b + lane);
-                            wk.ntok += (uint32_t)(__builtin_popcount(mlo) + __builtin_popcount(mhi));
+                        __builtin_amdgcn_wave_barrier();
+                        if ((uint32_t)lane < nseg) {
+                            uint32_t pp = segpos[lane];
+                            uint32_t slot = wk.ntok + segbase[lane];
+                            for (uint32_t cleft = count8[pp]; cleft; cleft--) {
+                                toklist[slot++] = (uint16_t)pp;
+                                const uint32_t sv = blen[pp];
+                                pp += sv >= minp ? sv : 1u;
+                            }
                         }
-                        wk.rd = wk.wr = b + pos;
-                        if (pos >= 64) continue;
+                        wk.ntok += total;
+                        wk.rd = wk.wr = pos;
+                        if (nseg) continue;
                     }
                     const uint32_t p = w_p0 + wk.rd;
                     if (p < n) {
