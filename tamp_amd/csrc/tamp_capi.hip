@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -129,6 +130,7 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
     // positions matched per epoch: the whole stream when it is short, else 2048 (LDS ~30 KB at W=1024,
     // five workgroups per CU); always a multiple of 64 (the walk chases 64 positions per register)
     uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
+    if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = blk < v ? blk : align_up(v, 64); }
     if (blk > 2048) blk = 2048;
     if (blk < 64) blk = 64;
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
@@ -257,14 +259,14 @@ const char* tamp_amd_last_error(void) { return t_last_error; }
 // debug-only: per-phase cycle counters (not part of the public header)
 int tamp_amd_prof_read(unsigned long long* out6) {
     if (!g_prof) {
-        if (hipMalloc(&g_prof, 64) != hipSuccess) return -1;
-        (void)hipMemset(g_prof, 0, 64);
-        for (int i = 0; i < 6; i++) out6[i] = 0;
+        if (hipMalloc(&g_prof, 128) != hipSuccess) return -1;
+        (void)hipMemset(g_prof, 0, 128);
+        for (int i = 0; i < 12; i++) out6[i] = 0;
         return 0;
     }
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(out6, g_prof, 48, hipMemcpyDeviceToHost);
-    (void)hipMemset(g_prof, 0, 64);
+    (void)hipMemcpy(out6, g_prof, 96, hipMemcpyDeviceToHost);
+    (void)hipMemset(g_prof, 0, 128);
     return 0;
 }
 #endif

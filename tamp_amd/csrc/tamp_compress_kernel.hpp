@@ -115,26 +115,22 @@ __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix)
            ((bytes4 >> 24) << (24 + kRemBits));
 }
 
-// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].
+// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  All five dwords are
+// fetched in one go (one LDS round trip) and the first differing byte is picked with selects, no early exits.
 __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
     const uint32_t sh = c & 3u;
-    uint32_t lo = w[0], hi = w[1];
-    uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[0];
-    if (x) return (uint32_t)__builtin_ctz(x) >> 3;
-    lo = hi;
-    hi = w[2];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[1];
-    if (x) return 4 + ((uint32_t)__builtin_ctz(x) >> 3);
-    lo = hi;
-    hi = w[3];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[2];
-    if (x) return 8 + ((uint32_t)__builtin_ctz(x) >> 3);
-    lo = hi;
-    hi = w[4];
-    x = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ P[3];
-    if (x) return 12 + ((uint32_t)__builtin_ctz(x) >> 3);
-    return 16;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ P[0];
+    const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ P[1];
+    const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ P[2];
+    const uint32_t x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ P[3];
+    uint32_t res = 16;
+    if (x3) res = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
+    if (x2) res = 8 + ((uint32_t)__builtin_ctz(x2) >> 3);
+    if (x1) res = 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+    if (x0) res = (uint32_t)__builtin_ctz(x0) >> 3;
+    return res;
 }
 
 // Candidate whose bytes run past the newest window byte: the ring continues with the OLDEST window byte, i.e.
@@ -384,7 +380,7 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // PACKED: u32 index entries (position | rest of bigram | next byte | 3 bits of the one after); otherwise u16
 // positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
 template <bool PACKED>
-__global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
+__global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
     const CompressLds L(W, a.blk, PACKED);
@@ -445,7 +441,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
         uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters
         bool need_match = true;
 #ifdef TAMP_PROF
-        unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long pc = __builtin_readcyclecounter();
 #endif
         for (;;) {
@@ -567,6 +563,13 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
 
                 // ---------------- match: find_best_match for every position of the block ----------------
                 const uint32_t nq = nvalid - e_pending;
+#ifdef TAMP_PROF
+                unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, niter = 0;
+#define TAMP_FINE(v) do { unsigned long long _n = __builtin_readcyclecounter(); v += _n - fc; fc = _n; } while (0)
+                unsigned long long fc = __builtin_readcyclecounter();
+#else
+#define TAMP_FINE(v) do { } while (0)
+#endif
                 for (uint32_t j = tid; j < nq; j += nt) {
                     const uint32_t q = sorted[j];
                     const uint32_t leftq = n - (e_p0 + q);
@@ -580,8 +583,16 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                         const uint32_t pk = entry_payload(P[0], mix16(P[0] & 0xFFFFu));
                         const uint32_t chi = q + W - 2;  // newest candidate served by the index
                         const uint32_t s_hi = bidx[q];
-                        for (uint32_t sl = qstart[q]; sl < s_hi; sl++) {
-                            const uint32_t e = PACKED ? ent[sl] : (uint32_t)ent16[sl];
+                        uint32_t sl = qstart[q];
+                        uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
+                        TAMP_FINE(f0);
+                        while (sl < s_hi) {
+#ifdef TAMP_PROF
+                            niter++;
+#endif
+                            const uint32_t e = e_next;
+                            sl++;
+                            e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // one past the range at the end: harmless
                             const uint32_t c = e & 0xFFFFu;
                             // position-only entries: everything is "deep", the byte compare decides
                             const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
@@ -597,6 +608,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                             const uint32_t k = (len << 16) | (0xFFFFu - i);
                             if (ok && len >= 2 && k > key) key = k;
                         }
+                        TAMP_FINE(f1);
                         {  // the newest window byte pairs with the OLDEST one: not in the index
                             const uint32_t c = q + W - 1;
                             const uint32_t i = (e_wp + c) & mask;
@@ -616,8 +628,13 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
                     }
                     blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
                     bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
+                    TAMP_FINE(f2);
                 }
                 __syncthreads();
+                TAMP_FINE(f3);
+#ifdef TAMP_PROF
+                pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[9] += f3, pt[10] += niter;
+#endif
                 for (uint32_t k = 4 + tid; k < 4 + a.blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
                 // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
@@ -886,7 +903,7 @@ __global__ void __launch_bounds__(256) tamp_compress_kernel(CompressArgs a) {
         }
 #ifdef TAMP_PROF
         if (tid == 0 && a.prof)
-            for (int i = 0; i < 6; i++) atomicAdd(&a.prof[i], pt[i]);
+            for (int i = 0; i < 12; i++) atomicAdd(&a.prof[i], pt[i]);
 #endif
         __syncthreads();  // ctl / LDS reuse by the next stream
     }
