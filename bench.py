@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--extended", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="streams timed on the host cores")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="streams timed on the host cores")
     args = ap.parse_args()
 
     import numpy as np
@@ -157,14 +157,31 @@ def cpu_baseline(args, rows, gpu_res, np):
     from tamp_amd import workloads as wl
 
     cores = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2 CPU quota of the container ("max" = unlimited)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
     sample = min(args.cpu_sample, rows.shape[0])
     sub = rows[:sample]
     off, ln = wl.csr_for_fixed(sample, rows.shape[1])
     kind, impl = ("reference", Ref()) if Ref.available() else ("port", Oracle())
+    kw = dict(window=args.window, literal=8, extended=bool(args.extended))
+    # the box may expose more logical CPUs than the container may use: pick the thread count on a small probe
+    probe = min(sample, 4096)
+    poff, pln = wl.csr_for_fixed(probe, rows.shape[1])
+    cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16, 8, quota or cores) if 1 <= c <= cores})
+    rates = {}
+    for c in cands:
+        r = impl.compress_batch(sub[:probe].reshape(-1), poff, pln, threads=c, **kw)
+        rates[c] = probe * rows.shape[1] / r.seconds
+    top = max(rates.values())
+    threads = min(c for c in cands if rates[c] >= 0.95 * top)  # fewest threads that reach the plateau
     best = None
     for _ in range(2):
-        r = impl.compress_batch(sub.reshape(-1), off, ln, window=args.window, literal=8, extended=bool(args.extended),
-                                threads=cores)
+        r = impl.compress_batch(sub.reshape(-1), off, ln, threads=threads, **kw)
         if best is None or r.seconds < best.seconds:
             best = r
     # parity of the GPU output against the baseline's output, stream by stream
@@ -180,9 +197,12 @@ def cpu_baseline(args, rows, gpu_res, np):
     return {
         "value": round(sub.size / best.seconds / 1e6, 2),
         "unit": "MB/s",
-        "cores": cores,
+        "cores": threads,
         "kind": kind,
-        "sample": f"first {sample} of the {rows.shape[0]} streams ({sub.size} B), {cores} pthreads, best of 2",
+        "sample": f"first {sample} of the {rows.shape[0]} streams ({sub.size} B), {threads} pthreads "
+                  f"(os.cpu_count()={cores}, cgroup cpu quota={quota}; thread count chosen on a {probe}-stream probe), "
+                  "best of 2",
+        "per_core": round(sub.size / best.seconds / 1e6 / threads, 2),
         "parity": "bit-exact" if mism < 0 else f"MISMATCH at stream {mism}",
     }
 
