@@ -160,6 +160,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     a.n_streams = (uint32_t)n_streams;
     a.prof = g_prof;
+    a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     const uint32_t W = 1u << conf->window;
     a.blk = pick_block(W, max_in_len);
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions

@@ -49,6 +49,7 @@ struct CompressArgs {
     uint32_t blk;  // epoch block: positions matched per epoch (multiple of 64)
     uint8_t wbits, lbits, extended, header, dict_reset;
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
+    uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
 };
 
 // LDS carve-up, shared by the host launcher and the kernel.
@@ -115,21 +116,21 @@ __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix)
            ((bytes4 >> 24) << (24 + kRemBits));
 }
 
-// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  All five dwords are
-// fetched in one go (one LDS round trip) and the first differing byte is picked with selects, no early exits.
+// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  Two stages of one LDS
+// round trip each: bytes 0..7 (where almost every candidate already differs), then 8..15.
 __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
     const uint32_t sh = c & 3u;
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
     const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ P[0];
     const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ P[1];
+    if (x0 | x1) return x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+    const uint32_t w3 = w[3], w4 = w[4];
     const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ P[2];
     const uint32_t x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ P[3];
     uint32_t res = 16;
     if (x3) res = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
     if (x2) res = 8 + ((uint32_t)__builtin_ctz(x2) >> 3);
-    if (x1) res = 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
-    if (x0) res = (uint32_t)__builtin_ctz(x0) >> 3;
     return res;
 }
 
@@ -570,6 +571,9 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
 #else
 #define TAMP_FINE(v) do { } while (0)
 #endif
+#ifdef TAMP_PROF
+                if (!(a.dbg & 1))
+#endif
                 for (uint32_t j = tid; j < nq; j += nt) {
                     const uint32_t q = sorted[j];
                     const uint32_t leftq = n - (e_p0 + q);
@@ -578,12 +582,16 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     uint32_t P[4];
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
+#ifdef TAMP_PROF
+                    if (R >= minp && !(a.dbg & 2)) {
+#else
                     if (R >= minp) {
+#endif
                         const uint32_t cap_len = R < maxp ? R : maxp;
                         const uint32_t pk = entry_payload(P[0], mix16(P[0] & 0xFFFFu));
                         const uint32_t chi = q + W - 2;  // newest candidate served by the index
                         const uint32_t s_hi = bidx[q];
-                        uint32_t sl = qstart[q];
+                        uint32_t sl = qstart[q], wrapmask = 0;
                         uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
                         TAMP_FINE(f0);
                         while (sl < s_hi) {
@@ -600,23 +608,30 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                             // in the window, same bigram, and not index W-1 (which cannot start a match)
                             const bool ok = c >= q && c <= chi && (x & ((1u << kRemBits) - 1)) == 0 && i != mask;
                             const uint32_t lim = min(cap_len, W - i);  // may not run past index W-1
-                            const bool wraps = c + 16 > q + W;
+                            const uint32_t t = q + W - c;              // bytes before the candidate reaches the newest byte
                             uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
-                            if (ok && (wraps || (x >> kRemBits) == 0))  // next two bytes agree too: compare for real
-                                len = wraps ? prefix_len_wrapped16(ebuf, c, q + W - c, W, P) : prefix_len16(ebuf, c, P);
-                            len = min(len, lim);
-                            const uint32_t k = (len << 16) | (0xFFFFu - i);
-                            if (ok && len >= 2 && k > key) key = k;
-                        }
-                        TAMP_FINE(f1);
-                        {  // the newest window byte pairs with the OLDEST one: not in the index
-                            const uint32_t c = q + W - 1;
-                            const uint32_t i = (e_wp + c) & mask;
-                            if (i != mask && ebuf[c] == (P[0] & 0xFFu)) {
-                                const uint32_t len = min(prefix_len_wrapped16(ebuf, c, 1, W, P), min(cap_len, W - i));
+                            if (ok && t < 16) {
+                                wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
+                            } else {
+                                if (ok && (x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                                len = min(len, lim);
                                 const uint32_t k = (len << 16) | (0xFFFFu - i);
-                                if (len >= 2 && k > key) key = k;
+                                if (ok && len >= 2 && k > key) key = k;
                             }
+                        }
+                        // Candidates in the last 15 window positions run past the newest byte, where the ring continues
+                        // with the OLDEST byte; t = 1 (the newest byte itself) pairs with the oldest one and is therefore
+                        // not in the index at all: test its first byte here.
+                        if (ebuf[q + W - 1] == (P[0] & 0xFFu)) wrapmask |= 2u;
+                        while (wrapmask) {
+                            const uint32_t t = (uint32_t)__builtin_ctz(wrapmask);
+                            wrapmask &= wrapmask - 1;
+                            const uint32_t c = q + W - t;
+                            const uint32_t i = (e_wp + c) & mask;
+                            if (i == mask) continue;
+                            const uint32_t len = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_len, W - i));
+                            const uint32_t k = (len << 16) | (0xFFFFu - i);
+                            if (len >= 2 && k > key) key = k;
                         }
                     }
                     const uint32_t len = key >> 16;
@@ -850,17 +865,18 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 nbytes = excess ? (tot >> 3) : ((tot + 7) >> 3);  // compressor.c:629-631 / :799-807
             else
                 nbytes = (tot >> 5) << 2;
-            {
+            {   // HBM stores are whole aligned dwords whatever the slab's byte alignment: a few head bytes, then
+                // dwords funnel-shifted out of the bit buffer, then the tail bytes
                 const uint8_t* ob = reinterpret_cast<const uint8_t*>(obuf);
                 uint8_t* dst = gout + gpos;
                 const uint32_t room2 = gpos < cap ? cap - gpos : 0;
                 const uint32_t nw = nbytes < room2 ? nbytes : room2;
-                if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
-                    for (uint32_t k = tid; k < (nw >> 2); k += nt) reinterpret_cast<uint32_t*>(dst)[k] = obuf[k];
-                    for (uint32_t k = (nw & ~3u) + tid; k < nw; k += nt) dst[k] = ob[k];
-                } else {
-                    for (uint32_t k = tid; k < nw; k += nt) dst[k] = ob[k];
-                }
+                const uint32_t head = min((uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nw);
+                const uint32_t ndw = (nw - head) >> 2;
+                if (tid < head) dst[tid] = ob[tid];
+                uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + head);
+                for (uint32_t k = tid; k < ndw; k += nt) dst32[k] = lds_u32_unaligned(ob, head + 4 * k);
+                for (uint32_t k = head + 4 * ndw + tid; k < nw; k += nt) dst[k] = ob[k];
             }
             if (act == kActDone) {
                 if (tid == 0) {
