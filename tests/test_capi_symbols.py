@@ -1,0 +1,86 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/tamp_amd.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "tamp_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(tamp_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_header_declares_the_boundary():
+    names = _declared_functions()
+    for must in ("tamp_batch_compress", "tamp_batch_decompress", "tamp_initialize_dictionary",
+                 "tamp_compute_min_pattern_size", "tamp_amd_compress", "tamp_amd_decompress", "tamp_amd_read_header"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)  # loading needs libamdhip64 but no GPU
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/tamp_amd.h but not exported"
+    assert set(_lib.SYMBOLS) == set(_declared_functions())
+
+
+def test_host_helpers_need_no_device(oracle):
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built")
+    lib = _lib.load()
+    buf = (ctypes.c_ubyte * 1024)()
+    for lit in (5, 6, 7, 8):
+        lib.tamp_initialize_dictionary(buf, 1024, lit)
+        assert bytes(buf) == oracle.initialize_dictionary(1024, lit)
+    for w in range(8, 16):
+        for lit in range(5, 9):
+            assert lib.tamp_compute_min_pattern_size(w, lit) == oracle.min_pattern_size(w, lit)
+    assert lib.tamp_amd_compress_bound(4096, 8, 0) == 4609
+    conf = _lib.TampAmdConf()
+    consumed = ctypes.c_size_t(0)
+    hdr = (ctypes.c_ubyte * 2)(0x5A, 0)
+    assert lib.tamp_amd_read_header(ctypes.byref(conf), hdr, 1, ctypes.byref(consumed)) == 0
+    assert (conf.window, conf.literal, conf.extended, conf.use_custom_dictionary, consumed.value) == (10, 8, 1, 0, 1)
+    hdr = (ctypes.c_ubyte * 2)(0x59, 1)
+    assert lib.tamp_amd_read_header(ctypes.byref(conf), hdr, 2, ctypes.byref(consumed)) == -3
+    assert lib.tamp_amd_read_header(ctypes.byref(conf), hdr, 1, ctypes.byref(consumed)) == 2
+
+
+def test_no_device_is_loud():
+    """Without a GPU the codec entry points must fail, never fall back to a CPU path."""
+    import tamp_amd
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        with pytest.raises(tamp_amd.NativeLibraryError):
+            tamp_amd.compress(b"abc")
+        return
+    if _lib.load().tamp_amd_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(tamp_amd.NativeLibraryError):
+        tamp_amd.compress(b"abc")
+    with pytest.raises(tamp_amd.NativeLibraryError):
+        tamp_amd.decompress(bytes.fromhex("58b3041c8100030000"))
+    with pytest.raises(tamp_amd.NativeLibraryError):
+        tamp_amd.compress_batch([b"abc", b"def"])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tamp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".c", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "libtamp_oracle" not in text and "libtamp_ref" not in text, f

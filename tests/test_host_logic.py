@@ -1,0 +1,90 @@
+"""CPU tier: host-side logic of the Python surface (no device): helpers, packing, sharding, argument checks."""
+import io
+
+import numpy as np
+import pytest
+
+import tamp_amd
+from tamp_amd import batch, sharding
+from conftest import load_golden
+
+
+def test_bit_size_and_min_pattern():
+    # tamp/__init__.py:18-23,66-70
+    assert [tamp_amd.bit_size(v) for v in (0, 1, 2, 255, 256, (1 << 31) - 1)] == [0, 1, 2, 8, 9, 31]
+    assert tamp_amd.bit_size(1 << 31) == -1  # the reference's loop stops at 32 iterations
+    assert tamp_amd.compute_min_pattern_size(10, 8) == 2
+    assert tamp_amd.compute_min_pattern_size(12, 5) == 3
+    with pytest.raises(ValueError):
+        tamp_amd.compute_min_pattern_size(16, 8)
+    with pytest.raises(ValueError):
+        tamp_amd.compute_min_pattern_size(10, 4)
+
+
+def test_initialize_dictionary_surface():
+    d = load_golden("dictionaries.json")
+    import os
+
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built")
+    out = tamp_amd.initialize_dictionary(256)  # tests/test_pseudorandom.py:22-24
+    assert isinstance(out, bytearray) and out.hex() == d["first256_literal8"]
+    buf = bytearray(256)
+    assert tamp_amd.initialize_dictionary(buf) is buf and buf.hex() == d["first256_literal8"]
+    assert tamp_amd.initialize_dictionary(256, seed=0) == bytearray(256)
+    assert tamp_amd.initialize_dictionary(256, seed=1) != bytearray(256)
+    assert tamp_amd.initialize_dictionary(256, seed=3758097560).hex() == d["first256_literal8"]
+    with pytest.raises(ValueError):
+        tamp_amd.initialize_dictionary(256, literal=4)
+
+
+def test_compress_bound_and_packing():
+    assert tamp_amd.compress_bound(4096, 8) == 4609
+    assert tamp_amd.compress_bound(0, 8) == 1
+    assert tamp_amd.compress_bound(256, 7, dictionary_reset=True) == 2 + 256
+    flat, off, ln = tamp_amd.pack_streams([b"abc", b"", b"defgh"])
+    assert flat.tobytes() == b"abcdefgh" and off.tolist() == [0, 3, 3] and ln.tolist() == [3, 0, 5]
+    offs, total = batch._slab_offsets(np.array([5, 0, 7], dtype=np.uint32))
+    assert offs.tolist() == [0, 5, 5] and total == 12
+
+
+def test_surface_argument_errors_need_no_device():
+    import os
+
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built")
+    with pytest.raises(ValueError):  # tests/test_compressor.py:196-205
+        tamp_amd.Compressor(io.BytesIO(), window=9, literal=7, dictionary=bytearray(256))
+    with pytest.raises(ValueError):  # tests/test_compressor.py:420-433
+        tamp_amd.Compressor(io.BytesIO(), literal=4)
+    with pytest.raises(ValueError):
+        tamp_amd.Compressor(io.BytesIO(), window=16)
+    with pytest.raises(ValueError):
+        tamp_amd.open(io.BytesIO(), "rw")
+    with pytest.raises(NotImplementedError):
+        tamp_amd.Compressor(io.BytesIO(), lazy_matching=True)
+    with pytest.raises(ValueError):
+        tamp_amd.compress_batch([b"x"], window=8, dictionary=bytes(100))
+
+
+def test_partition_streams():
+    assert sharding.partition_streams([4096] * 8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    assert sharding.partition_streams([4096] * 10, 4) == [(0, 3), (3, 5), (5, 8), (8, 10)]
+    parts = sharding.partition_streams([1, 1, 1000, 1, 1, 1], 3)
+    assert parts[0][0] == 0 and parts[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    assert sharding.partition_streams([], 3) == [(0, 0)] * 3
+    assert sharding.partition_streams([5, 5], 4)[-1][1] == 2
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 5000, 1000)
+    for ws in (1, 2, 3, 8):
+        parts = sharding.partition_streams(lens, ws)
+        assert parts[0][0] == 0 and parts[-1][1] == 1000
+        sums = [int(lens[a:b].sum()) for a, b in parts]
+        assert max(sums) - min(sums) <= 2 * 5000
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    b, e, lo, hi = sharding.shard_for_rank(off, lens, 1, 4)
+    assert lo == int(off[b]) and hi == int(off[e - 1] + lens[e - 1])
