@@ -186,8 +186,35 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
                       const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
                       size_t n_streams, hipStream_t st) {
     if (n_streams == 0) return TAMP_OK;
+    DecompressArgs a;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
+    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
+    a.in_consumed = d_consumed;
+    a.dict = d_dict, a.dict_len = (uint32_t)(dict_len > 0xFFFFFFFFu ? 0xFFFFFFFFu : dict_len);
+    a.seed_dicts = ctx->seed_dicts;
+    a.scratch = nullptr;
+    a.n_streams = (uint32_t)n_streams;
+    a.max_wbits = max_wbits;
+    a.lds_row = 0;
+    const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
+    if (valid_bits && max_wbits <= kLdsWinBits) {
+        // windows in LDS: one 64-lane workgroup per 64 streams, one padded row per lane
+        a.lds_row = (1u << max_wbits) + 4;
+        const uint32_t lds = kWave * a.lds_row;
+        const uint32_t per_cu = (uint32_t)(160 * 1024 / lds) < 16 ? (uint32_t)(160 * 1024 / lds) : 16;
+        size_t groups = (n_streams + kWave - 1) / kWave;
+        const size_t resident = (size_t)ctx->cu_count * per_cu;
+        if (groups > resident * 4) groups = resident * 4;  // grid-stride beyond a few waves of workgroups
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        timing_begin(st);
+        hipLaunchKernelGGL(tamp_decompress_kernel<true>, dim3((uint32_t)groups), dim3(kWave), lds, st, a);
+        timing_end(st);
+        HIP_OK(hipGetLastError());
+        return TAMP_OK;
+    }
     const uint32_t threads = 256;
-    const uint8_t slot_bits = (max_wbits >= 8 && max_wbits <= 15) ? max_wbits : 8;
+    const uint8_t slot_bits = valid_bits ? max_wbits : 8;
     const size_t slot = (size_t)1 << slot_bits;
     // resident lanes: enough to fill the chip, bounded by a 1 GiB window slab
     size_t lanes = (size_t)ctx->cu_count * 2048;
@@ -209,18 +236,9 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
             ctx->scratch_bytes = need;
         }
     }
-    DecompressArgs a;
-    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
-    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
-    a.in_consumed = d_consumed;
-    a.dict = d_dict, a.dict_len = (uint32_t)(dict_len > 0xFFFFFFFFu ? 0xFFFFFFFFu : dict_len);
-    a.seed_dicts = ctx->seed_dicts;
     a.scratch = ctx->scratch;
-    a.n_streams = (uint32_t)n_streams;
-    a.max_wbits = max_wbits;
-    if (!(max_wbits >= 8 && max_wbits <= 15)) a.scratch = ctx->scratch;  // kernel reports INVALID_CONF per stream
     timing_begin(st);
-    hipLaunchKernelGGL(tamp_decompress_kernel, dim3(grid), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL(tamp_decompress_kernel<false>, dim3(grid), dim3(threads), 0, st, a);
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;

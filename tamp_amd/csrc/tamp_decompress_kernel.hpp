@@ -5,8 +5,17 @@
 // prefix-code decode (:52-104), RLE / extended-match tokens (:114-273), the out-of-bounds rule
 // (:232-236,540-544) and the window update (common.c:58-86).  Decoding is bit-serial inside a stream
 // (SURVEY.md H5), so parallelism is across streams: 64 independent streams per wavefront, each lane
-// running the reference's token loop on its own bit buffer.  Windows of mixed sizes (8..15 bits, read
-// from each header) live in a per-lane slot of a global scratch slab that stays L2 / MALL resident.
+// running the reference's token loop on its own bit buffer.
+//
+//   * Windows up to 2^10 bytes live in LDS (one padded 1028-byte row per lane, conflict-free when the lanes
+//     touch the same index and spread over the banks otherwise): every back-reference byte is an LDS access
+//     instead of a divergent global one.  Larger windows (or mixed batches up to 2^15) use a per-lane slot of
+//     a global scratch slab that stays L2 / MALL resident.
+//   * A window slot that has not been written yet reads straight from the shared seed (or custom) dictionary,
+//     so no per-stream dictionary copy is made.
+//   * Compressed input is prefetched a dword at a time and output is written as aligned dwords; the logical
+//     byte-by-byte refill of the reference (which decides status and consumed counts on truncated input) is
+//     reproduced on top of that.
 #pragma once
 #include "tamp_common.hpp"
 
@@ -21,14 +30,18 @@ struct DecompressArgs {
     const uint32_t* out_cap;
     uint32_t* out_len;
     int8_t* status;
-    uint32_t* in_consumed;     // may be null
-    const uint8_t* dict;       // custom dictionary (>= 1<<window bytes) or null
+    uint32_t* in_consumed;      // may be null
+    const uint8_t* dict;        // custom dictionary (>= 1<<window bytes) or null
     uint32_t dict_len;
-    const uint8_t* seed_dicts; // 3 tables of 1<<15 bytes: literal<=5, literal==6, literal>=7 (common.c:18-25)
-    uint8_t* scratch;          // one window slot of (1 << max_wbits) bytes per resident lane
+    const uint8_t* seed_dicts;  // 3 tables of 1<<15 bytes: literal<=5, literal==6, literal>=7 (common.c:18-25)
+    uint8_t* scratch;           // global variant: one window slot of (1 << max_wbits) bytes per resident lane
     uint32_t n_streams;
+    uint32_t lds_row;           // LDS variant: bytes per lane row = (1 << max_wbits) + 4
     uint8_t max_wbits;
 };
+
+constexpr uint32_t kLdsWinBits = 10;  // largest window kept in LDS: 64 lanes x (2^10 + 4) B = 64.25 KiB per workgroup
+// padded row of (1 << max_wbits) + 4 bytes per lane: lane l, index i -> bank (l * (row/4) + i/4) % 64 = (l + i/4) % 64
 
 // Prefix-code reader for the symbol that follows the 0 flag (decompressor.c:52-104).  `b` holds the
 // upcoming bits left-aligned; returns the symbol and its code length, or -1 when `avail` is too small.
@@ -38,12 +51,15 @@ __device__ __forceinline__ int read_symbol(uint32_t b, uint32_t avail, uint32_t&
         used = 1;
         return 0;
     }
+    // code words (without the flag) are 2..8 bits; walk them from the packed tables
+    const uint64_t codes_lo = 0x2b2624140b080300ull, codes_hi = 0x00ab27aa9594544bull, nbits = 0x979998877765532ull;
     int sym = -1;
     uint32_t nb = 0;
 #pragma unroll
     for (int s = 1; s < 15; s++) {
-        const uint32_t l = d_nbits[s] - 1u;
-        if (sym < 0 && (b >> (32 - l)) == d_code[s]) {
+        const uint32_t l = (uint32_t)((nbits >> (4 * s)) & 15) - 1u;
+        const uint32_t code = (uint32_t)((s < 8 ? codes_lo >> (8 * s) : codes_hi >> (8 * (s - 8))) & 0xFF);
+        if (sym < 0 && (b >> (32 - l)) == code) {
             sym = s;
             nb = l;
         }
@@ -53,10 +69,12 @@ __device__ __forceinline__ int read_symbol(uint32_t b, uint32_t avail, uint32_t&
     return sym;
 }
 
-__global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) {
+template <bool LDSWIN>
+__global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(DecompressArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    uint8_t* const win = a.scratch + ((size_t)gtid << a.max_wbits);
+    uint8_t* const win = LDSWIN ? smem + threadIdx.x * a.lds_row : a.scratch + ((size_t)gtid << a.max_wbits);
 
     for (uint32_t s = gtid; s < a.n_streams; s += nthreads) {
         const uint8_t* const in = a.in + a.in_off[s];
@@ -65,6 +83,28 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
         const uint32_t cap = a.out_cap[s];
         uint32_t ip = 0, op = 0;
         int res = kInputExhausted;
+
+        // output staging: bytes collect in `oacc` and leave as one aligned dword
+        uint32_t oacc = 0, on = 0;
+        const bool out_aligned = (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+        auto emit = [&](uint32_t b) {
+            if (out_aligned) {
+                oacc |= b << (8 * on);
+                if (++on == 4) {
+                    *reinterpret_cast<uint32_t*>(out + op - 3) = oacc;
+                    oacc = 0;
+                    on = 0;
+                }
+            } else {
+                out[op] = (uint8_t)b;
+            }
+            op++;
+        };
+        auto emit_flush = [&]() {
+            for (uint32_t k = 0; k < on; k++) out[op - on + k] = (uint8_t)(oacc >> (8 * k));
+            on = 0;
+            oacc = 0;
+        };
 
         do {  // single pass; `break` = finished with `res`
             if (a.max_wbits < 8 || a.max_wbits > 15) { res = kInvalidConf; break; }  // decompressor.c:336
@@ -81,26 +121,44 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
             const uint32_t W = 1u << wbits, mask = W - 1;
             const uint32_t minp = (uint32_t)min_pattern_size((int)wbits, (int)lbits);
             const uint32_t table = (!extended || lbits >= 7) ? 2u : (lbits == 6 ? 1u : 0u);  // decompressor.c:318-319
-            const uint8_t* seed = a.seed_dicts + ((size_t)table << 15);
+            const uint8_t* const seed_default = a.seed_dicts + ((size_t)table << 15);
+            const uint8_t* seed = seed_default;
             if (custom) {
                 if (!a.dict || a.dict_len < W) { res = kInvalidConf; break; }
-                if ((reinterpret_cast<uintptr_t>(a.dict) & 3) == 0) {
-                    for (uint32_t k = 0; k < W; k += 4)
-                        *reinterpret_cast<uint32_t*>(win + k) = *reinterpret_cast<const uint32_t*>(a.dict + k);
-                } else {
-                    for (uint32_t k = 0; k < W; k++) win[k] = a.dict[k];
-                }
-            } else {
-                for (uint32_t k = 0; k < W; k += 4)
-                    *reinterpret_cast<uint32_t*>(win + k) = *reinterpret_cast<const uint32_t*>(seed + k);
+                seed = a.dict;
             }
+            // window[i] is the private copy once it has been written, the shared dictionary before that
+            uint32_t filled = 0;  // slots [0, filled) are private (saturates at W)
+            auto wread = [&](uint32_t i) -> uint32_t { return i < filled ? win[i] : seed[i]; };
+            uint32_t wp = 0;
+            auto wwrite = [&](uint32_t b) {
+                win[wp] = (uint8_t)b;
+                wp = (wp + 1) & mask;
+                if (filled < W) filled = wp ? (filled > wp ? filled : wp) : W;
+            };
 
-            uint32_t bb = 0, nb = 0, wp = 0;
+            // bit reader: `bb`/`nb` behave exactly like the reference's 32-bit buffer (decompressor.c:357-365);
+            // bytes are fetched from HBM a dword at a time into `stage`
+            uint32_t bb = 0, nb = 0;
+            uint32_t stage = 0, ns = 0;  // ns prefetched bytes, next one in the low byte
             bool last_flush = false;
-            auto refill = [&]() {  // decompressor.c:357-365
+            auto refill = [&]() {
                 while (ip < n && nb <= 24) {
+                    if (ns == 0) {
+                        const uint8_t* p = in + ip;
+                        if ((reinterpret_cast<uintptr_t>(p) & 3) == 0 && ip + 4 <= n) {
+                            stage = *reinterpret_cast<const uint32_t*>(p);
+                            ns = 4;
+                        } else {
+                            stage = *p;
+                            ns = 1;
+                        }
+                    }
                     nb += 8;
-                    bb |= (uint32_t)in[ip++] << (32 - nb);
+                    bb |= (stage & 0xFFu) << (32 - nb);
+                    stage >>= 8;
+                    ns--;
+                    ip++;
                 }
             };
 
@@ -113,12 +171,11 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
                 if (bb >> 31) {  // literal, decompressor.c:466-482
                     last_flush = false;
                     if (nb < 1 + lbits) break;
-                    const uint8_t c = (uint8_t)((bb << 1) >> (32 - lbits));
+                    const uint32_t c = (bb << 1) >> (32 - lbits);
                     bb <<= 1 + lbits;
                     nb -= 1 + lbits;
-                    out[op++] = c;
-                    win[wp] = c;
-                    wp = (wp + 1) & mask;
+                    emit(c);
+                    wwrite(c);
                     continue;
                 }
 
@@ -131,10 +188,10 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
                 if (sym == kSymFlush) {  // decompressor.c:501-514
                     bb = b2 << (n2 & 7);
                     nb = n2 & ~7u;
-                    if (dreset && last_flush) {
+                    if (dreset && last_flush) {  // double FLUSH: back to the pristine seeded dictionary
                         wp = 0;
-                        for (uint32_t k = 0; k < W; k += 4)
-                            *reinterpret_cast<uint32_t*>(win + k) = *reinterpret_cast<const uint32_t*>(seed + k);
+                        filled = 0;
+                        seed = seed_default;
                     }
                     last_flush = true;
                     continue;
@@ -176,27 +233,30 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
                     if (starved) break;
                     if (sym == kSymRle) {  // decompressor.c:140-173
                         const uint32_t count = value + 2;
-                        const uint8_t c = win[(wp - 1) & mask];
+                        const uint32_t c = wread((wp - 1) & mask);
                         const uint32_t room = cap - op;
                         const uint32_t w = count <= room ? count : room;
-                        for (uint32_t k = 0; k < w; k++) out[op + k] = c;
-                        op += w;
+                        for (uint32_t k = 0; k < w; k++) emit(c);
                         const uint32_t ww = min(min(count, kRleWindowMax), W - wp);
-                        for (uint32_t k = 0; k < ww; k++) win[wp + k] = c;
-                        wp = (wp + ww) & mask;
+                        for (uint32_t k = 0; k < ww; k++) wwrite(c);
                         if (w < count) { res = kOutputFull; break; }
                     } else {  // decompressor.c:229-272
                         if (off >= W || off + match_len > W) { res = kOob; break; }
                         const uint32_t room = cap - op;
                         const uint32_t w = match_len <= room ? match_len : room;
-                        for (uint32_t k = 0; k < w; k++) out[op + k] = win[off + k];
-                        if (w < match_len) { op += w; res = kOutputFull; break; }
-                        // window <- the same bytes, up to the end of the buffer, no wrap; sources are read from the
-                        // output just written, which gives tamp_window_copy's memmove semantics (common.c:58-86)
+                        for (uint32_t k = 0; k < w; k++) emit(wread(off + k));
+                        if (w < match_len) { res = kOutputFull; break; }
+                        // window <- the same bytes up to the end of the buffer, no wrap, memmove semantics
+                        // (tamp_window_copy, common.c:58-86): backwards when the destination runs into the source
                         const uint32_t ww = min(match_len, W - wp);
-                        for (uint32_t k = 0; k < ww; k++) win[wp + k] = out[op + k];
-                        wp = (wp + ww) & mask;
-                        op += w;
+                        const uint32_t dist = (wp - off) & mask;
+                        if (dist > 0 && dist < ww) {
+                            for (uint32_t k = ww; k-- > 0;) win[wp + k] = (uint8_t)wread(off + k);
+                            if (filled < W) filled = max(filled, wp + ww);
+                            wp = (wp + ww) & mask;
+                        } else {
+                            for (uint32_t k = 0; k < ww; k++) wwrite(wread(off + k));
+                        }
                     }
                     continue;
                 }
@@ -208,20 +268,31 @@ __global__ void __launch_bounds__(256) tamp_decompress_kernel(DecompressArgs a) 
                 if (off >= W || off + match_len > W) { res = kOob; break; }
                 const uint32_t room = cap - op;
                 if (match_len > room) {  // partial copy, token not consumed (decompressor.c:553-557)
-                    for (uint32_t k = 0; k < room; k++) out[op + k] = win[off + k];
-                    op += room;
+                    for (uint32_t k = 0; k < room; k++) emit(wread(off + k));
                     res = kOutputFull;
                     break;
                 }
                 bb = b2 << wbits;
                 nb = n2 - wbits;
-                for (uint32_t k = 0; k < match_len; k++) out[op + k] = win[off + k];
-                for (uint32_t k = 0; k < match_len; k++) win[(wp + k) & mask] = out[op + k];
-                wp = (wp + match_len) & mask;
-                op += match_len;
+                for (uint32_t k = 0; k < match_len; k++) emit(wread(off + k));
+                {  // tamp_window_copy: destination wraps, memmove semantics
+                    const uint32_t dist = (wp - off) & mask;
+                    if (dist > 0 && dist < match_len) {
+                        // reverse copy reads every source byte before it is overwritten; the private-copy
+                        // watermark must already cover the whole destination for wread() to stay consistent
+                        const uint32_t wp0 = wp;
+                        uint32_t tmp[4] = {0, 0, 0, 0};
+                        for (uint32_t k = 0; k < match_len; k++) tmp[k >> 2] |= wread(off + k) << (8 * (k & 3));
+                        for (uint32_t k = 0; k < match_len; k++) wwrite((tmp[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                        (void)wp0;
+                    } else {
+                        for (uint32_t k = 0; k < match_len; k++) wwrite(wread(off + k));
+                    }
+                }
             }
         } while (false);
 
+        emit_flush();
         a.out_len[s] = op;
         a.status[s] = (int8_t)res;
         if (a.in_consumed) a.in_consumed[s] = ip;
