@@ -186,6 +186,24 @@ struct Walk {
     // per-lane variants for the cooperative search
     __device__ __forceinline__ uint32_t win_l(uint32_t i) const { return ebuf[wr + ((i - wp()) & mask)]; }
     __device__ __forceinline__ uint32_t inb_l(uint32_t k) const { return ebuf[W + rd + k]; }
+    // Common prefix (<= lim) of the window from index i with either the window from index j (other_is_window) or the
+    // ring from byte j.  Dword compares while the window ranges stay on one side of the write cursor (contiguous in
+    // ebuf), byte compares for the remainder.
+    __device__ uint32_t common_l(uint32_t i, uint32_t j, uint32_t lim, bool other_is_window) const {
+        const uint32_t ri = (i - wp()) & mask, rj = (j - wp()) & mask;
+        const uint32_t a = wr + ri, b = other_is_window ? wr + rj : W + rd + j;
+        uint32_t contig = W - ri;  // bytes before index i's range passes the newest window byte
+        if (other_is_window) contig = min(contig, W - rj);
+        contig = min(contig, lim);
+        uint32_t nn = 0;
+        while (nn + 4 <= contig) {
+            const uint32_t x = lds_u32_unaligned(ebuf, a + nn) ^ lds_u32_unaligned(ebuf, b + nn);
+            if (x) return nn + ((uint32_t)__builtin_ctz(x) >> 3);
+            nn += 4;
+        }
+        while (nn < lim && win_l(i + nn) == (other_is_window ? win_l(j + nn) : inb_l(j + nn))) nn++;
+        return nn;
+    }
 
     // write_to_bit_buffer (compressor.c:49-52) becomes "append an explicit piece to the token list"
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb) {
@@ -247,16 +265,27 @@ struct Walk {
         const uint32_t maxp = min(cnt + R, minp + 11 + kExtExtraMax);
         const uint32_t nextb = inb(0);
         uint32_t key = 0;
-        for (uint32_t c = pos + lane; c + cnt + 1 <= W; c += kWave) {
-            if (win_l(c + cnt) != nextb) continue;
-            uint32_t i = 0;
-            while (i < cnt && win_l(c + i) == win_l(pos + i)) i++;
-            if (i < cnt) continue;
-            const uint32_t cmax = min(maxp, W - c);
-            uint32_t len = cnt + 1;
-            while (len < cmax && win_l(c + len) == inb_l(len - cnt)) len++;
-            uint32_t k = (len << 16) | (0xFFFFu - c);
-            if ((k >> 16) > (key >> 16)) key = k;  // first-longest within this lane (c ascending)
+        // 16 candidates per lane and pass: the "next byte matches" filter is 16 independent LDS reads (one round
+        // trip), only the rare survivors are verified byte by byte
+        for (uint32_t c0 = pos + lane; c0 + cnt + 1 <= W; c0 += 16 * kWave) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t c = c0 + k * kWave;
+                const bool valid = c + cnt + 1 <= W;
+                const uint32_t b = win_l(valid ? c + cnt : pos);
+                hits |= (uint32_t)(valid && b == nextb) << k;
+            }
+            while (hits) {
+                const uint32_t k = (uint32_t)__builtin_ctz(hits);
+                hits &= hits - 1;
+                const uint32_t c = c0 + k * kWave;
+                if (c != pos && common_l(c, pos, cnt, true) < cnt) continue;  // (the current position matches itself)
+                const uint32_t cmax = min(maxp, W - c);
+                const uint32_t len = cnt + 1 + common_l(c + cnt + 1, 1, cmax - cnt - 1, false);
+                const uint32_t kk = (len << 16) | (0xFFFFu - c);
+                if ((kk >> 16) > (key >> 16)) key = kk;  // first-longest within this lane (c ascending)
+            }
         }
         key = wave_max_u32(key);  // longest; ties -> lowest candidate
         ncnt = key >> 16;
@@ -286,6 +315,7 @@ struct Walk {
                         return kStepOk;
                     }
                     uint32_t npos, ncnt;
+                    const uint32_t reach = min(ext_count + R, max_ext);  // the search's own cap (compressor.c:308)
                     ext_search(R, npos, ncnt);
                     if (ncnt > ext_count) {
                         uint32_t extra = ncnt - ext_count;
@@ -293,7 +323,10 @@ struct Walk {
                         ext_count = ncnt;
                         rd += extra;
                         R -= extra;
-                        continue;
+                        // No candidate matched more than ncnt bytes of (pattern + ring).  Unless the cap stopped
+                        // it, the reference's next search (same bytes, a subset of the candidates) finds nothing
+                        // and emits the token; skip straight to that.
+                        if (ncnt == reach) continue;
                     }
                     emit_ext();
                     return kStepOk;
@@ -303,7 +336,16 @@ struct Walk {
             // RLE accumulation, compressor.c:470-525
             const uint32_t last = win((wp() - 1) & mask);
             uint32_t avail = 0;
-            while (avail < R && rle_count + avail < kRleMax && inb(avail) == last) avail++;
+            {   // leading ring bytes equal to `last`: 16 bytes compared at once (first differing byte via ctz)
+                const uint32_t rep = last * 0x01010101u;
+                uint32_t run = 16;
+#pragma unroll
+                for (int j = 3; j >= 0; j--) {
+                    const uint32_t x = uni(lds_u32_unaligned(ebuf, W + rd + 4 * j)) ^ rep;
+                    if (x) run = 4 * j + ((uint32_t)__builtin_ctz(x) >> 3);
+                }
+                avail = min(min(run, R), kRleMax - rle_count);
+            }
             const uint32_t total = rle_count + avail;
             const bool ended = (avail < R) || (total >= kRleMax);
             if (!ended && total > 0) {
@@ -359,7 +401,7 @@ struct Walk {
 
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
 // ctl words
-enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cWave = 8 };
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8 };
 
 #ifdef TAMP_PROF
 #define TAMP_PROF_MARK(i)                                     \
@@ -441,16 +483,20 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         uint32_t gpos = 0;                         // bytes already flushed to HBM
         uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters
         bool need_match = true;
+        // Positions matched per epoch.  A token that breaks the speculation throws the rest of the block away, so
+        // after such a break the next block is small (data with long runs / window-end truncations tends to break
+        // again soon); a block that ends cleanly doubles it back up to the LDS capacity.
+        uint32_t cur_blk = a.blk;
 #ifdef TAMP_PROF
         unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long pc = __builtin_readcyclecounter();
 #endif
         for (;;) {
             const uint32_t left = n - e_p0;
-            const uint32_t nvalid = left < a.blk ? left : a.blk;
+            const uint32_t nvalid = left < cur_blk ? left : cur_blk;
             if (need_match) {
                 // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
-                const uint32_t room = a.blk + kRing + kPendMax;
+                const uint32_t room = cur_blk + kRing + kPendMax;
                 const uint32_t nload = left < room ? left : room;
                 {
                     const uint8_t* src = in + e_p0;
@@ -582,10 +628,16 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     uint32_t P[4];
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
+                    // Inside a run of one byte the extended state machine never asks for a match: with the previous
+                    // byte and the next seven all equal, the RLE path owns the position (compressor.c:470-503 only
+                    // consults find_best_match for runs of 2..6).  Skipping the scan there removes the worst buckets.
+                    const uint32_t rep = (P[0] & 0xFFu) * 0x01010101u;
+                    const bool in_run = ext && R >= 7 && ebuf[W + q - 1] == (P[0] & 0xFFu) && P[0] == rep &&
+                                        (P[1] & 0x00FFFFFFu) == (rep & 0x00FFFFFFu);
 #ifdef TAMP_PROF
-                    if (R >= minp && !(a.dbg & 2)) {
+                    if (R >= minp && !in_run && !(a.dbg & 2)) {
 #else
-                    if (R >= minp) {
+                    if (R >= minp && !in_run) {
 #endif
                         const uint32_t cap_len = R < maxp ? R : maxp;
                         const uint32_t pk = entry_payload(P[0], mix16(P[0] & 0xFFFFu));
@@ -648,7 +700,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 __syncthreads();
                 TAMP_FINE(f3);
 #ifdef TAMP_PROF
-                pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[9] += f3, pt[10] += niter;
+                pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[10] += niter;
 #endif
                 for (uint32_t k = 4 + tid; k < 4 + a.blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
                 // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
@@ -722,9 +774,18 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     if (p < n) {
                         const uint32_t pending = wk.rle_count + wk.ext_count;
                         int r = Walk::kStepRebase;
-                        if (wk.rd <= a.blk + pending) {
+                        if (wk.rd <= cur_blk + pending) {
                             const uint32_t leftp = n - p;
+#ifdef TAMP_PROF
+                            const unsigned long long t0 = __builtin_readcyclecounter();
+                            const uint32_t ec0 = wk.ext_count;
+#endif
                             r = wk.step(leftp < kRing ? leftp : kRing);
+#ifdef TAMP_PROF
+                            pt[11] += 1;
+                            if (ec0) pt[5] += __builtin_readcyclecounter() - t0;  // time in extended-match continuation steps
+                            else pt[9] += __builtin_readcyclecounter() - t0;      // other slow steps
+#endif
                         }
                         if (r == Walk::kStepRebase) {
                             act = kActRebase;
@@ -756,6 +817,11 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     // written (oracle/tamp_model.c m_epoch_begin)
                     const uint32_t pending = wk.rle_count + wk.ext_count;
                     const uint32_t shift = wk.wr;
+                    // broke inside the block (lag) -> quarter it; ran off its end -> double it
+                    const bool broke = wk.wr + pending != wk.rd;  // bytes were consumed that will never be written
+                    uint32_t nb2 = broke ? max(cur_blk >> 2, 256u) : min(cur_blk << 1, a.blk);
+                    nb2 = min(nb2, a.blk);
+                    if (lane == 0) ctl[cBlk] = nb2;
                     wk.wp_e = wk.wp();
                     w_p0 += wk.rd - pending;
                     wk.wr = 0;
@@ -903,6 +969,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 e_p0 = ctl[cP0];
                 e_pending = ctl[cPending];
                 e_wp = ctl[cWp];
+                cur_blk = ctl[cBlk];
                 // re-base: ebuf[0..W) <- ebuf[shift..shift+W) (moving left, chunked)
                 if (shift) {
                     for (uint32_t base = 0; base < W; base += nt * 4) {
