@@ -15,6 +15,7 @@
 #include "tamp_amd.h"
 #include "tamp_compress_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
+#include "tamp_decompress_wave_kernel.hpp"
 
 using namespace tamp_amd;
 
@@ -197,6 +198,25 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.max_wbits = max_wbits;
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
+    // Decoder choice: one wavefront per stream (scalar token loop, window in LDS, 64-lane copies) unless the batch is
+    // a very large number of streams, where one lane per stream fills the chip and avoids per-stream set-up.
+    const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" (tuning / tests)
+    const bool many = n_streams >= ((size_t)1 << 19);
+    const bool use_wave = force ? (force[0] == 'w') : !(many && max_wbits <= kLdsWinBits);
+    if (valid_bits && use_wave) {
+        const uint32_t waves = max_wbits <= 12 ? 4 : 1;
+        const uint32_t lds = decode_wave_lds(max_wbits, waves);
+        size_t groups = (n_streams + waves - 1) / waves;
+        const size_t resident = (size_t)ctx->cu_count * 64;
+        if (groups > resident) groups = resident;  // grid-stride beyond that
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_wave_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        timing_begin(st);
+        hipLaunchKernelGGL(tamp_decompress_wave_kernel, dim3((uint32_t)groups), dim3(waves * kWave), lds, st, a);
+        timing_end(st);
+        HIP_OK(hipGetLastError());
+        return TAMP_OK;
+    }
     if (valid_bits && max_wbits <= kLdsWinBits) {
         // windows in LDS: one 64-lane workgroup per 64 streams, one padded row per lane
         a.lds_row = (1u << max_wbits) + 4;
