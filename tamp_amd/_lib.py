@@ -31,6 +31,14 @@ SYMBOLS = (
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
+    # include/tamp_compat.h: the reference's own symbol names for the one-shot path
+    "tamp_compressor_init",
+    "tamp_compressor_compress_and_flush_cb",
+    "tamp_compressor_compress_and_flush",
+    "tamp_decompressor_read_header",
+    "tamp_decompressor_init",
+    "tamp_decompressor_decompress_cb",
+    "tamp_decompressor_decompress",
 )
 
 

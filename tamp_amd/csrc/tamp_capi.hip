@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "tamp_amd.h"
+#include "tamp_compat.h"
 #include "tamp_compress_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
@@ -499,6 +500,180 @@ tamp_res tamp_amd_read_header(TampAmdConf* conf, const unsigned char* input, siz
     conf->dictionary_reset = input[0] & 1;
     if (input_consumed_size) *input_consumed_size = hs;
     return TAMP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The reference's own symbol names for the one-shot path (include/tamp_compat.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct CompressorPriv {  // lives in TampCompressor::private_ (40 bytes)
+    uint32_t magic;
+    TampConf conf;
+    uint8_t used;
+};
+struct DecompressorPriv {  // lives in TampDecompressor::private_ (16 bytes)
+    uint32_t magic;
+    TampConf conf;
+    uint8_t has_conf, used, window_bits;
+};
+constexpr uint32_t kMagicC = 0x74616d43u, kMagicD = 0x74616d44u;
+static_assert(sizeof(TampConf) == 2, "TampConf must match the reference (common.h:170-182)");
+static_assert(sizeof(TampCompressor) == 48, "TampCompressor must match the reference (compressor.h:13-66)");
+static_assert(sizeof(TampDecompressor) == 24, "TampDecompressor must match the reference (decompressor.h:13-57)");
+static_assert(sizeof(CompressorPriv) <= 40 && sizeof(DecompressorPriv) <= 16, "private state must fit");
+int compat_device() {
+    const char* e = getenv("TAMP_AMD_DEVICE");
+    return e ? atoi(e) : 0;
+}
+}  // namespace
+
+tamp_res tamp_compressor_init(TampCompressor* compressor, const TampConf* conf, unsigned char* window) {
+    TampConf dflt;
+    std::memset(&dflt, 0, sizeof dflt);
+    dflt.window = 10, dflt.literal = 8, dflt.extended = 1;  // compressor.c:193-203
+    if (!conf) conf = &dflt;
+    if (conf->window < 8 || conf->window > 15 || conf->literal < 5 || conf->literal > 8) return TAMP_INVALID_CONF;
+    if (conf->append && (!conf->dictionary_reset || conf->use_custom_dictionary)) return TAMP_INVALID_CONF;
+    std::memset(compressor, 0, sizeof *compressor);
+    compressor->window = window;
+    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
+    p->magic = kMagicC, p->conf = *conf, p->used = 0;
+    if (!conf->use_custom_dictionary)  // compressor.c:224-225
+        seed_dictionary_host(window, (size_t)1 << conf->window, conf->extended ? conf->literal : 8);
+    return TAMP_OK;
+}
+
+tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                               size_t* output_written_size, const unsigned char* input,
+                                               size_t input_size, size_t* input_consumed_size, bool write_token,
+                                               tamp_callback_t callback, void* user_data) {
+    if (output_written_size) *output_written_size = 0;
+    if (input_consumed_size) *input_consumed_size = 0;
+    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
+    if (p->magic != kMagicC) return TAMP_ERROR;
+    if (p->used || write_token || p->conf.append || p->conf.lazy_matching) {
+        snprintf(t_last_error, sizeof t_last_error,
+                 "tamp_compressor_compress_and_flush: only one whole-stream call with write_token=false on a fresh "
+                 "compressor is supported (no state carry-over, no lazy matching yet)");
+        return TAMP_ERROR;
+    }
+    TampAmdConf c;
+    std::memset(&c, 0, sizeof c);
+    c.window = p->conf.window, c.literal = p->conf.literal, c.extended = p->conf.extended;
+    c.use_custom_dictionary = p->conf.use_custom_dictionary, c.dictionary_reset = p->conf.dictionary_reset;
+    size_t written = 0;
+    tamp_res r = tamp_amd_compress(&c, c.use_custom_dictionary ? compressor->window : nullptr, output, output_size,
+                                   &written, input, input_size, compat_device());
+    if (output_written_size) *output_written_size = written;
+    p->used = 1;
+    if (r == TAMP_OK) {
+        if (input_consumed_size) *input_consumed_size = input_size;
+        if (callback) {  // final "100 %" callback, compressor.c:836-842
+            int cb = callback(user_data, input_size, input_size);
+            if (cb) return (tamp_res)cb;
+        }
+    }
+    return r;
+}
+
+tamp_res tamp_compressor_compress_and_flush(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                            size_t* output_written_size, const unsigned char* input, size_t input_size,
+                                            size_t* input_consumed_size, bool write_token) {
+    return tamp_compressor_compress_and_flush_cb(compressor, output, output_size, output_written_size, input,
+                                                 input_size, input_consumed_size, write_token, nullptr, nullptr);
+}
+
+tamp_res tamp_decompressor_read_header(TampConf* conf, const unsigned char* input, size_t input_size,
+                                       size_t* input_consumed_size) {
+    TampAmdConf c;
+    tamp_res r = tamp_amd_read_header(&c, input, input_size, input_consumed_size);
+    if (r != TAMP_OK) return r;
+    conf->window = c.window, conf->literal = c.literal, conf->use_custom_dictionary = c.use_custom_dictionary;
+    conf->extended = c.extended, conf->dictionary_reset = c.dictionary_reset;
+    return TAMP_OK;
+}
+
+tamp_res tamp_decompressor_init(TampDecompressor* decompressor, const TampConf* conf, unsigned char* window,
+                                uint8_t window_bits) {
+    if (window_bits < 8 || window_bits > 15) return TAMP_INVALID_CONF;  // decompressor.c:336
+    std::memset(decompressor, 0, sizeof *decompressor);
+    decompressor->window = window;
+    DecompressorPriv* p = reinterpret_cast<DecompressorPriv*>(decompressor->private_);
+    p->magic = kMagicD, p->window_bits = window_bits, p->used = 0, p->has_conf = conf != nullptr;
+    if (conf) {
+        if (conf->window < 8 || conf->window > 15 || conf->literal < 5 || conf->literal > 8) return TAMP_INVALID_CONF;
+        if (conf->window > window_bits) return TAMP_INVALID_CONF;  // decompressor.c:311
+        p->conf = *conf;
+    }
+    return TAMP_OK;
+}
+
+tamp_res tamp_decompressor_decompress_cb(TampDecompressor* decompressor, unsigned char* output, size_t output_size,
+                                         size_t* output_written_size, const unsigned char* input, size_t input_size,
+                                         size_t* input_consumed_size, tamp_callback_t callback, void* user_data) {
+    if (output_written_size) *output_written_size = 0;
+    if (input_consumed_size) *input_consumed_size = 0;
+    DecompressorPriv* p = reinterpret_cast<DecompressorPriv*>(decompressor->private_);
+    if (p->magic != kMagicD) return TAMP_ERROR;
+    if (p->used) {
+        if (input_size == 0) return TAMP_INPUT_EXHAUSTED;  // "nothing more to do" after the one whole-stream call
+        snprintf(t_last_error, sizeof t_last_error,
+                 "tamp_decompressor_decompress: resuming a stream needs state carry-over (not in this release)");
+        return TAMP_ERROR;
+    }
+    // the stream as the kernel wants it: header first.  When init was given a conf the caller's input starts after
+    // the header (tamp/_c_decompressor.pyx:50-75): put one back in front.
+    std::vector<unsigned char> buf;
+    const unsigned char* src = input;
+    size_t n = input_size, hdr = 0;
+    bool custom;
+    if (p->has_conf) {
+        hdr = 1 + (p->conf.dictionary_reset ? 1 : 0);
+        buf.resize(hdr + input_size);
+        buf[0] = (unsigned char)(((p->conf.window - 8) << 5) | ((p->conf.literal - 5) << 3) |
+                                 (p->conf.use_custom_dictionary << 2) | (p->conf.extended << 1) |
+                                 p->conf.dictionary_reset);
+        if (hdr == 2) buf[1] = 0;
+        if (input_size) std::memcpy(buf.data() + hdr, input, input_size);
+        src = buf.data(), n = buf.size();
+        custom = p->conf.use_custom_dictionary;
+    } else {
+        custom = input_size > 0 && ((input[0] >> 2) & 1);
+    }
+    const size_t dict_len = custom ? (size_t)1 << p->window_bits : 0;  // the caller's window holds the dictionary
+    size_t written = 0, consumed = 0;
+    tamp_res r;
+    {
+        if (n > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+        const uint64_t zero = 0;
+        const uint32_t ilen = (uint32_t)n;
+        const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+        uint32_t olen = 0, icons = 0;
+        int8_t st = TAMP_ERROR;
+        static const unsigned char empty = 0;
+        // max_window_bits = the caller's buffer size: a header asking for more is TAMP_INVALID_CONF (decompressor.c:311)
+        int rc = tamp_batch_decompress(custom ? decompressor->window : nullptr, dict_len, p->window_bits,
+                                       n ? src : &empty, &zero, &ilen, output, &zero, &ocap, &olen, &st, &icons, 1,
+                                       TAMP_AMD_MEM_HOST, compat_device(), nullptr);
+        r = rc != TAMP_OK ? (tamp_res)rc : st;
+        written = olen, consumed = icons;
+    }
+    if (output_written_size) *output_written_size = written;
+    if (input_consumed_size) *input_consumed_size = consumed > hdr ? consumed - hdr : 0;
+    p->used = 1;
+    if (r >= 0 && callback) {
+        int cb = callback(user_data, input_size, input_size);
+        if (cb) return (tamp_res)cb;
+    }
+    return r;
+}
+
+tamp_res tamp_decompressor_decompress(TampDecompressor* decompressor, unsigned char* output, size_t output_size,
+                                      size_t* output_written_size, const unsigned char* input, size_t input_size,
+                                      size_t* input_consumed_size) {
+    return tamp_decompressor_decompress_cb(decompressor, output, output_size, output_written_size, input, input_size,
+                                           input_consumed_size, nullptr, nullptr);
 }
 
 }  // extern "C"

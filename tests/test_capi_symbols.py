@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "tamp_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b(tamp_[a-z0-9_]+)\s*\(", text))
+    names = set()
+    for header in ("tamp_amd.h", "tamp_compat.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(tamp_[a-z0-9_]+)\s*\(", text))
+    names.discard("tamp_callback_t")
     return sorted(names)
 
 
@@ -84,3 +87,37 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "libtamp_oracle" not in text and "libtamp_ref" not in text, f
+
+
+def test_c_caller_compiles_and_links(tmp_path):
+    """A plain C translation unit (the shape of tools/c-profiler/main.c:52-54 in the reference) builds against
+    include/tamp_compat.h and links with libtamp_amd.so; host helpers run without a device."""
+    import shutil
+    import subprocess
+
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH) or not shutil.which("gcc"):
+        pytest.skip("library or gcc missing")
+    src = tmp_path / "caller.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "tamp_compat.h"\n'
+        "int main(void) {\n"
+        "  unsigned char window[1 << 10], out[64];\n"
+        "  TampCompressor c; TampDecompressor d; TampConf conf = {.window = 10, .literal = 8, .extended = 1};\n"
+        '  printf("%zu %zu %zu %d ", sizeof(TampConf), sizeof(TampCompressor), sizeof(TampDecompressor),\n'
+        "         (int)tamp_compute_min_pattern_size(10, 8));\n"
+        "  if (tamp_compressor_init(&c, &conf, window) != TAMP_OK) return 1;\n"
+        "  if (tamp_decompressor_init(&d, NULL, window, 10) != TAMP_OK) return 2;\n"
+        "  if (tamp_compressor_init(&c, &(TampConf){.window = 10, .literal = 4}, window) != TAMP_INVALID_CONF) return 3;\n"
+        '  printf("%02x%02x%02x%02x\\n", window[0], window[1], window[2], window[3]);\n'
+        "  (void)out; (void)tamp_compressor_compress_and_flush; (void)tamp_decompressor_decompress;\n"
+        "  return 0;\n}\n"
+    )
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                           str(exe), "-L", libdir, "-ltamp_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out[:4] == ["2", "48", "24", "2"]
+    assert out[4] == "002e2f2f"  # tests/test_pseudorandom.py:22-24: dictionary starts 00 '.' '/' '/'

@@ -240,3 +240,71 @@ def test_long_single_stream(ta, oracle):
         res = ta.compress_batch([data], **conf)
         assert int(res.status[0]) == st and res.stream(0) == want, conf
         assert ta.decompress(want) == data
+
+
+def test_reference_named_c_api(ta, oracle):
+    """include/tamp_compat.h: the reference's own symbols (ctests/test_compressor.c round-trip shape) via ctypes."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    comp_t, decomp_t = C.c_ubyte * 48, C.c_ubyte * 24
+    lib.tamp_compressor_init.restype = C.c_int8
+    lib.tamp_compressor_compress_and_flush.restype = C.c_int8
+    lib.tamp_compressor_compress_and_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_bool]
+    lib.tamp_decompressor_init.restype = C.c_int8
+    lib.tamp_decompressor_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8]
+    lib.tamp_decompressor_decompress.restype = C.c_int8
+    lib.tamp_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p,
+                                                 C.c_size_t, C.POINTER(C.c_size_t)]
+    data = wl.synth_text(1, 3000)[0].tobytes()
+    for kw in (dict(window=10, literal=8, extended=1), dict(window=10, literal=8, extended=0),
+               dict(window=9, literal=8, extended=1, use_custom_dictionary=1)):
+        conf = TampConf(**kw)
+        W = 1 << conf.window
+        window = (C.c_ubyte * W)()
+        dic = None
+        if conf.use_custom_dictionary:
+            dic = wl.synth_text(1, W, first_index=77)[0].tobytes()
+            C.memmove(window, dic, W)
+        c = comp_t()
+        assert lib.tamp_compressor_init(c, C.byref(conf), window) == 0
+        out = (C.c_ubyte * 4096)()
+        written, consumed = C.c_size_t(0), C.c_size_t(0)
+        src = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        r = lib.tamp_compressor_compress_and_flush(c, out, 4096, C.byref(written), src, len(data), C.byref(consumed), False)
+        st, want = oracle.compress(data, window=conf.window, literal=8, extended=bool(conf.extended), dictionary=dic)
+        assert (r, bytes(out[: written.value]), consumed.value) == (st, want, len(data))
+        # a second call on the same object would need carried state: refused, not emulated
+        assert lib.tamp_compressor_compress_and_flush(c, out, 4096, C.byref(written), src, 10, C.byref(consumed), False) == -1
+        # decode: conf from the header ...
+        if dic is not None:
+            C.memmove(window, dic, W)
+        d = decomp_t()
+        assert lib.tamp_decompressor_init(d, None, window, conf.window) == 0
+        back = (C.c_ubyte * 4096)()
+        cbuf = (C.c_ubyte * len(want)).from_buffer_copy(want)
+        r = lib.tamp_decompressor_decompress(d, back, 4096, C.byref(written), cbuf, len(want), C.byref(consumed))
+        assert (r, bytes(back[: written.value]), consumed.value) == (2, data, len(want))
+        # ... or handed to init, with the input starting after the header (the Cython binding's way)
+        d = decomp_t()
+        assert lib.tamp_decompressor_init(d, C.byref(conf), window, conf.window) == 0
+        cbuf = (C.c_ubyte * (len(want) - 1)).from_buffer_copy(want[1:])
+        r = lib.tamp_decompressor_decompress(d, back, 4096, C.byref(written), cbuf, len(want) - 1, C.byref(consumed))
+        assert (r, bytes(back[: written.value]), consumed.value) == (2, data, len(want) - 1)
+    # decompressor.c:311: header asks for a bigger window than the caller's buffer
+    d = decomp_t()
+    window = (C.c_ubyte * 256)()
+    assert lib.tamp_decompressor_init(d, None, window, 8) == 0
+    want = oracle.compress(b"abcabcabc")[1]
+    cbuf = (C.c_ubyte * len(want)).from_buffer_copy(want)
+    assert lib.tamp_decompressor_decompress(d, (C.c_ubyte * 64)(), 64, None, cbuf, len(want), None) == -3
