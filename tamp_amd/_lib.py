@@ -117,5 +117,5 @@ def check_launch(rc: int) -> None:
         raise NativeLibraryError("tamp_amd: no HIP device available or a HIP runtime call failed "
                                  f"[{detail}]; the codec only runs on the GPU")
     if rc == BAD_ARGUMENT:
-        raise ValueError("tamp_amd: bad argument (lazy_matching is not supported yet; pointers/sizes invalid)")
+        raise ValueError("tamp_amd: bad argument (invalid pointers / sizes / configuration)")
     raise RuntimeError(f"tamp_amd: unexpected return code {rc}")

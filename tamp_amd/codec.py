@@ -51,8 +51,6 @@ class Compressor:
             raise ValueError("Dictionary-window size mismatch.")
         if not (8 <= window <= 15 and 5 <= literal <= 8):
             raise ValueError  # tamp_compressor_init -> TAMP_INVALID_CONF -> ValueError
-        if lazy_matching:
-            raise NotImplementedError("lazy_matching: SURVEY.md section 8f row 1 (next)")
         if dictionary_reset or append:
             raise NotImplementedError("dictionary_reset / append: SURVEY.md section 8f row 2 (next)")
         if not hasattr(f, "write"):
@@ -61,7 +59,8 @@ class Compressor:
         else:
             self._close_f_on_close = False
         self.f = f
-        self._conf = TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), 0, 0)
+        self._conf = TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), 0,
+                                 int(bool(lazy_matching)))
         self._dictionary = bytes(dictionary) if dictionary is not None else None
         self._dictionary_reset = dictionary_reset
         self._pending = bytearray()

@@ -149,6 +149,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
     a.wbits = conf->window, a.lbits = conf->literal, a.extended = conf->extended != 0;
     a.dict_reset = conf->dictionary_reset != 0;
+    a.lazy = conf->lazy_matching != 0;
     // header byte, compressor.c:236-241
     a.header = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) |
                          ((conf->use_custom_dictionary != 0) << 2) | ((conf->extended != 0) << 1) |
@@ -166,7 +167,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     const uint32_t W = 1u << conf->window;
     a.blk = pick_block(W, max_in_len);
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
-    const CompressLds L(W, a.blk, packed);
+    const CompressLds L(W, a.blk, packed, a.lazy != 0);
     if (L.total > ctx->lds_per_block) {
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
         return TAMP_AMD_BAD_ARGUMENT;
@@ -329,7 +330,6 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         return TAMP_AMD_BAD_ARGUMENT;
     if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
     if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
-    if (conf->lazy_matching) return TAMP_AMD_BAD_ARGUMENT;  // not in this release
     DeviceCtx* ctx = nullptr;
     int rc = get_ctx(device, &ctx);
     if (rc != TAMP_OK) return rc;
@@ -552,16 +552,17 @@ tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsig
     if (input_consumed_size) *input_consumed_size = 0;
     CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
     if (p->magic != kMagicC) return TAMP_ERROR;
-    if (p->used || write_token || p->conf.append || p->conf.lazy_matching) {
+    if (p->used || write_token || p->conf.append) {
         snprintf(t_last_error, sizeof t_last_error,
                  "tamp_compressor_compress_and_flush: only one whole-stream call with write_token=false on a fresh "
-                 "compressor is supported (no state carry-over, no lazy matching yet)");
+                 "compressor is supported (no state carry-over yet)");
         return TAMP_ERROR;
     }
     TampAmdConf c;
     std::memset(&c, 0, sizeof c);
     c.window = p->conf.window, c.literal = p->conf.literal, c.extended = p->conf.extended;
     c.use_custom_dictionary = p->conf.use_custom_dictionary, c.dictionary_reset = p->conf.dictionary_reset;
+    c.lazy_matching = p->conf.lazy_matching;
     size_t written = 0;
     tamp_res r = tamp_amd_compress(&c, c.use_custom_dictionary ? compressor->window : nullptr, output, output_size,
                                    &written, input, input_size, compat_device());

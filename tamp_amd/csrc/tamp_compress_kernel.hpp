@@ -47,16 +47,16 @@ struct CompressArgs {
     const uint8_t* dict;  // 1<<wbits bytes: the custom dictionary or the seeded default
     uint32_t n_streams;
     uint32_t blk;  // epoch block: positions matched per epoch (multiple of 64)
-    uint8_t wbits, lbits, extended, header, dict_reset;
+    uint8_t wbits, lbits, extended, header, dict_reset, lazy;
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
 };
 
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
-    uint32_t ebuf, cnt, ent, blen, bidx, obuf, ctl, total;
+    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, total;  // blen2/bidx2: lazy-matching probe results
     uint32_t tokcap, obuf_words, jump, count;  // jump/count: byte offsets of the walk's tables inside `ent`
-    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed) {
+    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
@@ -78,6 +78,10 @@ struct CompressLds {
         o += align_up(blk + 128, 16);
         bidx = o;
         o += align_up(blk * 2, 16);
+        blen2 = o;
+        if (lazy) o += align_up(blk + 16, 16);
+        bidx2 = o;
+        if (lazy) o += align_up(blk * 2 + 16, 16);
         obuf_words = ((blk + kPendMax + kRing + 64) * 9 + kSlowCap * 25) / 32 + 8;
         if (obuf_words < 4 + blk / 2) obuf_words = 4 + blk / 2;  // words 4.. hold the u16 scan starts during match
         obuf = o;
@@ -173,6 +177,11 @@ struct Walk {
     uint32_t nvalid;
     uint32_t rle_count, ext_count, ext_pos;
     uint32_t ntok, ns;
+    bool lazy;           // lazy matching (compressor.c:576-619)
+    bool lazy_valid;     // a match cached by the previous step's probe
+    uint32_t lazy_idx, lazy_len;
+    const uint8_t* blen2;   // probe results: best match of the pattern at q+1 in the window as it is at q
+    const uint16_t* bidx2;
     int lane;
 
     // The walk's scalars are identical in all 64 lanes; values that come back from LDS are passed through
@@ -308,6 +317,7 @@ struct Walk {
         uint32_t idx = 0, len = 0;
         if (ext) {
             if (ext_count) {  // compressor.c:439-468
+                lazy_valid = false;  // extended handling consumes input: any cached lazy match is stale (:563-568)
                 const uint32_t max_ext = minp + 11 + kExtExtraMax;
                 while (R > 0) {
                     if (ext_pos + ext_count >= W || ext_count >= max_ext) {
@@ -351,6 +361,7 @@ struct Walk {
             if (!ended && total > 0) {
                 rle_count = total;
                 rd += avail;
+                lazy_valid = false;
                 return kStepOk;
             }
             if (total >= 2) {
@@ -366,16 +377,43 @@ struct Walk {
                     rd += avail;
                     emit_rle(total);
                     rle_count = 0;
+                    lazy_valid = false;
                     return kStepOk;
                 }
             } else if (rle_count == 1) {
                 put((1u << lbits) | last, lbits + 1);
                 append(1, wr + 1 == rd, [&](uint32_t) { return last; });
                 rle_count = 0;
+                lazy_valid = false;
                 return kStepOk;
             }
         }
-        if (len == 0 && !best(idx, len)) return kStepRebase;
+        if (lazy) {  // compressor.c:576-619
+            uint32_t cidx = lazy_idx, clen = lazy_len;
+            const bool from_cache = lazy_valid;
+            if (!from_cache) {
+                cidx = idx, clen = len;
+                if (clen == 0 && !best(cidx, clen)) return kStepRebase;
+            }
+            bool defer = false;
+            uint32_t nidx = 0, nlen = 0;
+            if (clen >= minp && clen <= 8 && R > clen + 2) {
+                // probe position+1 against the window as it is now: precomputed next to the match tables
+                if (wr != rd || rd + 1 >= nvalid) return kStepRebase;  // nothing has been changed yet
+                nlen = uni(blen2[rd]);
+                nidx = uni(bidx2[rd]);
+                const uint32_t wpos = wp();
+                defer = nlen > clen && (wpos < nidx || wpos >= nidx + nlen);  // validate_no_match_overlap, :185-188
+            }
+            idx = cidx, len = clen;
+            lazy_valid = false;
+            if (defer) {
+                lazy_valid = true, lazy_idx = nidx, lazy_len = nlen;
+                len = 0;  // literal now, the better match at the next position
+            }
+        } else if (len == 0 && !best(idx, len)) {
+            return kStepRebase;
+        }
 
         if (len < minp) {  // literal, compressor.c:625-632
             const uint32_t c = inb(0);
@@ -426,7 +464,8 @@ template <bool PACKED>
 __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
-    const CompressLds L(W, a.blk, PACKED);
+    const bool lazy = a.lazy != 0;
+    const CompressLds L(W, a.blk, PACKED, lazy);
     uint8_t* const ebuf = smem + L.ebuf;
     uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
     uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
@@ -440,6 +479,8 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
     uint8_t* const blen = smem + L.blen;
     uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
+    uint8_t* const blen2 = smem + L.blen2;                                    // only carved when lazy
+    uint16_t* const bidx2 = reinterpret_cast<uint16_t*>(smem + L.bidx2);
     uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
     uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
     uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
@@ -476,6 +517,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
         wk.wp_e = 0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
         wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+        wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
         // workgroup-uniform output state
@@ -625,6 +667,14 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     const uint32_t leftq = n - (e_p0 + q);
                     const uint32_t R = leftq < kRing ? leftq : kRing;
                     uint32_t key = 0;
+                    // lazy matching: the same pattern also probes the window as it was one position earlier (window
+                    // start q-1, one byte less look-ahead): compressor.c:585-596 restated per position
+                    uint32_t keyB = 0, wrapmaskB = 0, cap_lenB = 0;
+                    if (lazy && q >= 1) {
+                        const uint32_t leftp = n - (e_p0 + q - 1);
+                        const uint32_t Rb = (leftp < kRing ? leftp : kRing) - 1;
+                        cap_lenB = Rb >= minp ? (Rb < maxp ? Rb : maxp) : 0;
+                    }
                     uint32_t P[4];
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
@@ -632,7 +682,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     // byte and the next seven all equal, the RLE path owns the position (compressor.c:470-503 only
                     // consults find_best_match for runs of 2..6).  Skipping the scan there removes the worst buckets.
                     const uint32_t rep = (P[0] & 0xFFu) * 0x01010101u;
-                    const bool in_run = ext && R >= 7 && ebuf[W + q - 1] == (P[0] & 0xFFu) && P[0] == rep &&
+                    const bool in_run = ext && !lazy && R >= 7 && ebuf[W + q - 1] == (P[0] & 0xFFu) && P[0] == rep &&
                                         (P[1] & 0x00FFFFFFu) == (rep & 0x00FFFFFFu);
 #ifdef TAMP_PROF
                     if (R >= minp && !in_run && !(a.dbg & 2)) {
@@ -658,17 +708,31 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                             const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
                             const uint32_t i = (e_wp + c) & mask;  // window index of the candidate
                             // in the window, same bigram, and not index W-1 (which cannot start a match)
-                            const bool ok = c >= q && c <= chi && (x & ((1u << kRemBits) - 1)) == 0 && i != mask;
+                            const bool same = (x & ((1u << kRemBits) - 1)) == 0 && i != mask;
+                            const bool ok = c >= q && c <= chi && same;
+                            const bool okB = cap_lenB && c >= q && c + 1 <= chi && same;  // window [q-1, q+W-1); c = q-1 apart
                             const uint32_t lim = min(cap_len, W - i);  // may not run past index W-1
                             const uint32_t t = q + W - c;              // bytes before the candidate reaches the newest byte
                             uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
-                            if (ok && t < 16) {
-                                wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
-                            } else {
-                                if (ok && (x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
-                                len = min(len, lim);
-                                const uint32_t k = (len << 16) | (0xFFFFu - i);
-                                if (ok && len >= 2 && k > key) key = k;
+                            if ((ok || okB) && (x >> kRemBits) == 0 && t > 16) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                            if (ok) {
+                                if (t < 16) {
+                                    wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
+                                } else {
+                                    const uint32_t la = t == 16 && (x >> kRemBits) == 0 ? prefix_len16(ebuf, c, P) : len;
+                                    const uint32_t l2 = min(la, lim);
+                                    const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                                    if (l2 >= 2 && k > key) key = k;
+                                }
+                            }
+                            if (okB) {
+                                if (t <= 16) {
+                                    wrapmaskB |= 1u << (t - 1);
+                                } else {
+                                    const uint32_t l2 = min(len, min(cap_lenB, W - i));
+                                    const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                                    if (l2 >= 2 && k > keyB) keyB = k;
+                                }
                             }
                         }
                         // Candidates in the last 15 window positions run past the newest byte, where the ring continues
@@ -686,10 +750,35 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                             if (len >= 2 && k > key) key = k;
                         }
                     }
+                    if (cap_lenB) {
+                        {   // oldest byte of the earlier window: outside this query's bracket, test it directly
+                            const uint32_t c = q - 1, i = (e_wp + c) & mask;
+                            if (i != mask) {
+                                const uint32_t l2 = min(prefix_len16(ebuf, c, P), min(cap_lenB, W - i));
+                                const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                                if (l2 >= 2 && k > keyB) keyB = k;
+                            }
+                        }
+                        if (ebuf[q + W - 2] == (P[0] & 0xFFu)) wrapmaskB |= 2u;  // newest byte of that window pairs with its oldest
+                        while (wrapmaskB) {
+                            const uint32_t t = (uint32_t)__builtin_ctz(wrapmaskB);
+                            wrapmaskB &= wrapmaskB - 1;
+                            const uint32_t c = q - 1 + W - t;
+                            const uint32_t i = (e_wp + c) & mask;
+                            if (i == mask) continue;
+                            const uint32_t l2 = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_lenB, W - i));
+                            const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                            if (l2 >= 2 && k > keyB) keyB = k;
+                        }
+                    }
+                    if (lazy && q >= 1) {
+                        blen2[q - 1] = (uint8_t)(keyB >> 16);
+                        bidx2[q - 1] = (uint16_t)(0xFFFFu - (keyB & 0xFFFFu));
+                    }
                     const uint32_t len = key >> 16;
                     // positions where poll_extended_handling does more than fall through (compressor.c:470-503)
-                    bool slow = false;
-                    if (ext) {
+                    bool slow = lazy;  // lazy matching: every step goes through the state machine
+                    if (ext && !slow) {
                         const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
                         slow = (prev == b0 && (b1 == b0 || R == 1)) || len > minp + 11;
                     }

@@ -94,8 +94,6 @@ def test_generated_reference_outputs(ta):
     groups = {}
     rows_cache = {}
     for c in g["cases"]:
-        if c["conf"].get("lazy_matching"):
-            continue  # next
         wlname = c["workload"]
         if wlname not in rows_cache:
             need = 1 + max(k["index"] for k in g["cases"] if k["workload"] == wlname)
@@ -139,9 +137,10 @@ def test_differential_vs_oracle(ta, oracle):
     from tamp_amd import workloads as wl
 
     rng = random.Random(7)
-    for it in range(60):
+    for it in range(90):
         w, lit = rng.randrange(8, 16), rng.randrange(5, 9)
         ext = rng.random() < 0.6
+        lazy = rng.random() < 0.35
         d = None
         if rng.random() < 0.3:
             d = (_rand_inputs(rng, wl, 1 << w) + bytes(1 << w))[: 1 << w]
@@ -152,12 +151,12 @@ def test_differential_vs_oracle(ta, oracle):
             if lit < 8 and rng.random() < 0.9:
                 x = bytes(b & ((1 << lit) - 1) for b in x)
             datas.append(x)
-        res = ta.compress_batch(datas, window=w, literal=lit, extended=ext, dictionary=d)
+        res = ta.compress_batch(datas, window=w, literal=lit, extended=ext, dictionary=d, lazy_matching=lazy)
         comps = []
         for j, x in enumerate(datas):
-            st, want = oracle.compress(x, window=w, literal=lit, extended=ext, dictionary=d)
-            assert int(res.status[j]) == st, (it, j, w, lit, ext, len(x))
-            assert res.stream(j) == want, (it, j, w, lit, ext, len(x))
+            st, want = oracle.compress(x, window=w, literal=lit, extended=ext, dictionary=d, lazy_matching=lazy)
+            assert int(res.status[j]) == st, (it, j, w, lit, ext, lazy, len(x))
+            assert res.stream(j) == want, (it, j, w, lit, ext, lazy, len(x))
             comps.append(want)
         # decode: exact, short and corrupted streams
         dec_in, caps = [], []

@@ -66,7 +66,7 @@ def test_surface_argument_errors_need_no_device():
     with pytest.raises(ValueError):
         tamp_amd.open(io.BytesIO(), "rw")
     with pytest.raises(NotImplementedError):
-        tamp_amd.Compressor(io.BytesIO(), lazy_matching=True)
+        tamp_amd.Compressor(io.BytesIO(), dictionary_reset=True)
     with pytest.raises(ValueError):
         tamp_amd.compress_batch([b"x"], window=8, dictionary=bytes(100))
 
