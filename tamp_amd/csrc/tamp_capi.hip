@@ -174,7 +174,8 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     const uint32_t threads = a.blk >= 1024 ? 256 : 64;
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
-    auto kernel = packed ? tamp_compress_kernel<true> : tamp_compress_kernel<false>;
+    auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true> : tamp_compress_kernel<false, true>)
+                         : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
     timing_begin(st);

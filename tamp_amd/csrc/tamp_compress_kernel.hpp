@@ -460,11 +460,12 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // ---------------------------------------------------------------------------------------------
 // PACKED: u32 index entries (position | rest of bigram | next byte | 3 bits of the one after); otherwise u16
 // positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
-template <bool PACKED>
+// LAZY: lazy matching (compressor.c:576-619) compiled in; the default build carries none of its code.
+template <bool PACKED, bool LAZY>
 __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
-    const bool lazy = a.lazy != 0;
+    constexpr bool lazy = LAZY;
     const CompressLds L(W, a.blk, PACKED, lazy);
     uint8_t* const ebuf = smem + L.ebuf;
     uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
