@@ -680,11 +680,17 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
                     // Inside a run of one byte the extended state machine never asks for a match: with the previous
-                    // byte and the next seven all equal, the RLE path owns the position (compressor.c:470-503 only
-                    // consults find_best_match for runs of 2..6).  Skipping the scan there removes the worst buckets.
+                    // byte repeated 7+ times ahead, or up to the end of the ring, the RLE path owns the position
+                    // (compressor.c:470-503 only consults find_best_match for runs of 2..6 that END inside the ring).
+                    // Skipping the scan there removes the worst buckets.
                     const uint32_t rep = (P[0] & 0xFFu) * 0x01010101u;
-                    const bool in_run = ext && !lazy && R >= 7 && ebuf[W + q - 1] == (P[0] & 0xFFu) && P[0] == rep &&
-                                        (P[1] & 0x00FFFFFFu) == (rep & 0x00FFFFFFu);
+                    bool in_run = false;
+                    if (ext && !lazy && ebuf[W + q - 1] == (P[0] & 0xFFu)) {
+                        // r = leading ring bytes equal to the previous byte, looked at up to 7
+                        const uint32_t x0 = P[0] ^ rep, x1 = (P[1] ^ rep) & 0x00FFFFFFu;
+                        const uint32_t r = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : (x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : 7u);
+                        in_run = r >= 7 || r >= R;  // the run reaches past the arbitration limit or to the end of the ring
+                    }
 #ifdef TAMP_PROF
                     if (R >= minp && !in_run && !(a.dbg & 2)) {
 #else
