@@ -147,6 +147,24 @@ tamp_res tamp_amd_decompress(const unsigned char *dictionary, size_t dictionary_
                              size_t output_size, size_t *output_written_size, const unsigned char *input,
                              size_t input_size, size_t *input_consumed_size, int device);
 
+/*
+ * One SEGMENT of a stream: the bytes between two flush points, with the window carried in and out.  It is what the
+ * reference's streaming calls add up to between flushes -- tamp_compressor_init (compressor.h:84; header, or with
+ * conf.append the FLUSH marker of compressor.c:227-235), any number of tamp_compressor_compress (compressor.h:244)
+ * and one tamp_compressor_flush(write_token) (compressor.h:193; FLUSH rule compressor.c:776-794) -- and is what
+ * tamp_amd.Compressor.write()/flush()/reset_dictionary() are built from.  A segment always ends byte aligned, so the
+ * carried state is just the window (1<<window bytes, ring order) and window_pos.
+ *   emit_header / append_marker   how the segment opens: header byte(s), the 2-byte FLUSH marker, or nothing
+ *   resume                        0: fresh stream (window_state holds the custom dictionary if conf says so, else it is
+ *                                 ignored on input); 1: continue from window_state / *window_pos
+ *   flush_token                   write_token of tamp_compressor_flush; *token_written tells whether one was emitted
+ * window_state / *window_pos are updated on TAMP_OK.  Host buffers, one stream, device `device`.
+ */
+tamp_res tamp_amd_compress_segment(const TampAmdConf *conf, int emit_header, int append_marker, int resume,
+                                   int flush_token, unsigned char *window_state, uint16_t *window_pos,
+                                   unsigned char *output, size_t output_size, size_t *output_written_size,
+                                   const unsigned char *input, size_t input_size, int *token_written, int device);
+
 /* Replaces tamp_decompressor_read_header (decompressor.h:67, decompressor.c:276-297): host-side header parse. */
 tamp_res tamp_amd_read_header(TampAmdConf *conf, const unsigned char *input, size_t input_size,
                               size_t *input_consumed_size);

@@ -144,6 +144,70 @@ class Oracle(_Base):
                                      C.byref(n))
         return r, out[: n.value].tobytes()
 
+    def stream_script(self, ops, *, window=10, literal=8, extended=True, dictionary=None, dictionary_reset=False,
+                      append=False, lazy_matching=False):
+        """Same op script as ``Ref.stream_script`` replayed on the restatement: bytes between flush points form one
+        ``oracle_compress_segment`` call; last_was_flush is tracked here (compressor.c:234,548,784,864)."""
+        L = self.lib
+        L.oracle_compress_segment.restype = C.c_int
+        L.oracle_compress_segment.argtypes = [C.POINTER(_OracleConf)] + [C.c_int] * 4 + [
+            C.c_void_p, C.POINTER(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+            C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        if not (8 <= window <= 15 and 5 <= literal <= 8) or (append and (not dictionary_reset or dictionary is not None)):
+            return INVALID_CONF, b""
+        conf = _OracleConf(window, literal, int(dictionary is not None), int(extended), int(dictionary_reset),
+                           int(lazy_matching))
+        win = np.zeros(1 << window, dtype=np.uint8)
+        if dictionary is not None:
+            win[:] = _u8(dictionary)
+        wp = C.c_uint16(0)
+        st = dict(opened=False, resume=False, lwf=bool(append))
+        pending, emitted = bytearray(), bytearray()
+
+        def segment(flush_token):
+            n = len(pending)
+            if n:
+                st["lwf"] = False
+            want = bool(flush_token) and not st["lwf"]
+            a = _u8(bytes(pending))
+            out = np.zeros(worst_case_compressed_size(n, literal, True) + 8, dtype=np.uint8)
+            k, tok = C.c_size_t(0), C.c_int(0)
+            r = L.oracle_compress_segment(C.byref(conf), int(not st["opened"] and not append),
+                                          int(not st["opened"] and append), int(st["resume"]), int(want), _p(win),
+                                          C.byref(wp), _p(a) if n else None, n, _p(out), len(out), C.byref(k),
+                                          C.byref(tok))
+            emitted.extend(out[: k.value].tobytes())
+            if r == OK:
+                st["opened"] = st["resume"] = True
+                pending.clear()
+                if tok.value:
+                    st["lwf"] = True
+            return r
+
+        for op in ops:
+            r = OK
+            if op[0] == "write":
+                pending.extend(bytes(op[1]))
+            elif op[0] == "flush":
+                r = segment(bool(op[1]))
+            elif op[0] == "close":
+                r = segment(dictionary_reset)
+            elif op[0] == "reset":
+                if not dictionary_reset:
+                    return INVALID_CONF, bytes(emitted)
+                for _ in range(2):
+                    st["lwf"] = False
+                    r = segment(True)
+                    if r != OK:
+                        break
+                st["resume"] = False
+                conf.use_custom_dictionary = 0
+                wp = C.c_uint16(0)
+                st["lwf"] = bool(append)
+            if r != OK:
+                return r, bytes(emitted)
+        return OK, bytes(emitted)
+
     def decompress(self, data, *, dictionary=None, cap=None, max_window_bits=15):
         """-> (status, bytes, consumed)"""
         a = _u8(data)
@@ -171,6 +235,47 @@ class Ref(_Base):
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ref_initialize_dictionary.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         L.ref_min_pattern_size.restype = C.c_int
+        L.ref_stream_new.restype = C.c_void_p
+        L.ref_stream_new.argtypes = [C.c_int] * 7 + [C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_stream_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
+        L.ref_stream_flush.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ref_stream_reset_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ref_stream_free.argtypes = [C.c_void_p]
+
+    def stream_script(self, ops, *, window=10, literal=8, extended=True, dictionary=None, dictionary_reset=False,
+                      append=False, lazy_matching=False):
+        """Replay ``ops`` -- ("write", bytes) | ("flush", write_token) | ("reset",) | ("close",) -- on ONE reference
+        compressor object, the way tamp/_c_compressor.pyx drives it.  Returns (res, bytes emitted so far)."""
+        d = _u8(dictionary) if dictionary is not None else None
+        res = C.c_int(0)
+        h = self.lib.ref_stream_new(window, literal, int(dictionary is not None), int(extended), int(dictionary_reset),
+                                    int(append), int(lazy_matching), _p(d) if d is not None else None, C.byref(res))
+        emitted = bytearray()
+        try:
+            if res.value < 0:
+                return res.value, bytes(emitted)
+            for op in ops:
+                n = C.c_size_t(0)
+                if op[0] == "write":
+                    a = _u8(op[1])
+                    out = np.zeros(worst_case_compressed_size(len(a), literal, True) + 64, dtype=np.uint8)
+                    r = self.lib.ref_stream_write(h, _p(a), len(a), _p(out), len(out), C.byref(n)) if len(a) else 0
+                elif op[0] in ("flush", "close"):
+                    out = np.zeros(64, dtype=np.uint8)
+                    tok = bool(op[1]) if op[0] == "flush" else bool(dictionary_reset)
+                    r = self.lib.ref_stream_flush(h, int(tok), _p(out), 32, C.byref(n))
+                elif op[0] == "reset":
+                    out = np.zeros(64, dtype=np.uint8)
+                    r = self.lib.ref_stream_reset_dictionary(h, _p(out), 32, C.byref(n))
+                else:
+                    raise ValueError(op[0])
+                emitted += out[: n.value].tobytes()
+                if r < 0:
+                    return r, bytes(emitted)
+            return 0, bytes(emitted)
+        finally:
+            self.lib.ref_stream_free(h)
 
     @staticmethod
     def available() -> bool:

@@ -69,6 +69,51 @@ int ref_decompress(const unsigned char *in, size_t n, const unsigned char *dict,
     return res;
 }
 
+/* ---- streaming calls, one reference object driven op by op (goldens for tests/golden/streaming.json) ---- */
+
+typedef struct {
+    TampCompressor c;
+    unsigned char window[1 << 15];
+} RefStream;
+
+void *ref_stream_new(int window, int literal, int custom, int extended, int dictionary_reset, int append, int lazy,
+                     const unsigned char *dict, int *res_out) {
+    RefStream *s = (RefStream *)calloc(1, sizeof *s);
+    TampConf conf;
+    memset(&conf, 0, sizeof conf);
+    conf.window = (uint16_t)window;
+    conf.literal = (uint16_t)literal;
+    conf.use_custom_dictionary = custom != 0;
+    conf.extended = extended != 0;
+    conf.dictionary_reset = dictionary_reset != 0;
+    conf.append = append != 0;
+#if TAMP_LAZY_MATCHING
+    conf.lazy_matching = lazy != 0;
+#else
+    (void)lazy;
+#endif
+    if (custom && dict) memcpy(s->window, dict, (size_t)1 << window);
+    int res = tamp_compressor_init(&s->c, &conf, s->window);
+    if (res_out) *res_out = res;
+    return s;
+}
+
+int ref_stream_write(void *h, const unsigned char *in, size_t n, unsigned char *out, size_t cap, size_t *written) {
+    RefStream *s = (RefStream *)h;
+    size_t consumed = 0;
+    return tamp_compressor_compress(&s->c, out, cap, written, in, n, &consumed);
+}
+
+int ref_stream_flush(void *h, int write_token, unsigned char *out, size_t cap, size_t *written) {
+    return tamp_compressor_flush(&((RefStream *)h)->c, out, cap, written, write_token != 0);
+}
+
+int ref_stream_reset_dictionary(void *h, unsigned char *out, size_t cap, size_t *written) {
+    return tamp_compressor_reset_dictionary(&((RefStream *)h)->c, out, cap, written);
+}
+
+void ref_stream_free(void *h) { free(h); }
+
 /* ---- multi-threaded batch drivers for the cpu_baseline leg of bench.py ---- */
 
 typedef struct {

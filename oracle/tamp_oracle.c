@@ -340,15 +340,13 @@ static int enc_step(Enc *e, unsigned R) {
     return ORACLE_OK;
 }
 
-int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *in, size_t n, uint8_t *out,
-                    size_t cap, size_t *out_len) {
+/* Core of every compress entry point: one SEGMENT = lead bits (header, append marker or nothing), the
+ * reference's sink/poll loop over `in`, then tamp_compressor_flush(write_token).  `win` is the caller's window
+ * (already seeded or carried over), *wp its write cursor. */
+static int compress_core(const OracleConf *conf, uint8_t *win, uint32_t *wp, uint32_t lead, unsigned lead_bits,
+                         const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, int flush_token,
+                         int *token_written) {
     static uint8_t dummy;
-    if (out_len) *out_len = 0;
-    if (conf->window < 8 || conf->window > 15) return ORACLE_INVALID_CONF; /* compressor.c:208-209 */
-    if (conf->literal < 5 || conf->literal > 8) return ORACLE_INVALID_CONF;
-    if (conf->use_custom_dictionary && !dict) return ORACLE_INVALID_CONF;
-
-    uint8_t win[1 << 15];
     Enc e;
     memset(&e, 0, sizeof e);
     e.in = in ? in : &dummy;
@@ -356,6 +354,7 @@ int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *
     e.win = win;
     e.W = 1u << conf->window;
     e.mask = e.W - 1;
+    e.wp = *wp & e.mask;
     e.wbits = conf->window;
     e.lbits = conf->literal;
     e.minp = (unsigned)oracle_min_pattern_size(conf->window, conf->literal);
@@ -364,18 +363,8 @@ int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *
     e.lazy_idx = -1;
     e.bs.out = out;
     e.bs.cap = cap;
-    if (conf->use_custom_dictionary)
-        memcpy(win, dict, e.W);
-    else
-        oracle_initialize_dictionary(win, e.W, conf->extended ? conf->literal : 8); /* compressor.c:224-225 */
-
-    /* header, compressor.c:236-241 */
-    put_bits(&e.bs,
-             ((uint32_t)(conf->window - 8) << 5) | ((uint32_t)(conf->literal - 5) << 3) |
-                 ((uint32_t)(conf->use_custom_dictionary != 0) << 2) | ((uint32_t)(conf->extended != 0) << 1) |
-                 (uint32_t)(conf->dictionary_reset != 0),
-             8);
-    if (conf->dictionary_reset) put_bits(&e.bs, 0, 8);
+    if (token_written) *token_written = 0;
+    if (lead_bits) put_bits(&e.bs, lead, lead_bits);
 
     int res = ORACLE_OK;
     /* tamp_compressor_compress_cb (compressor.c:681-722): refill the ring, step only while it is full. */
@@ -391,7 +380,7 @@ int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *
             }
         }
     }
-    /* tamp_compressor_flush(write_token=false) (compressor.c:728-810): drain with shrinking look-ahead. */
+    /* tamp_compressor_flush (compressor.c:728-810): drain with shrinking look-ahead. */
     for (;;) {
         if (e.p < n) {
             size_t whole_before = e.bs.nbytes;
@@ -415,9 +404,66 @@ int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *
             break;
         }
     }
+    /* FLUSH token only when bits are pending or the stream is a dictionary_reset one (compressor.c:784-794);
+     * the caller has already folded last_was_flush into flush_token. */
+    if (flush_token && (e.bs.nacc || conf->dictionary_reset)) {
+        put_bits(&e.bs, k_code[SYM_FLUSH], k_nbits[SYM_FLUSH]);
+        if (token_written) *token_written = 1;
+    }
     if (e.bs.nacc) put_bits(&e.bs, 0, 8 - e.bs.nacc); /* zero-pad the last byte, compressor.c:799-807 */
     if (out_len) *out_len = e.bs.nbytes < cap ? e.bs.nbytes : cap;
+    *wp = e.wp;
     return e.bs.overflow ? ORACLE_OUTPUT_FULL : ORACLE_OK;
+}
+
+static uint32_t header_bits(const OracleConf *conf, unsigned *nbits) { /* compressor.c:236-241 */
+    uint32_t h = ((uint32_t)(conf->window - 8) << 5) | ((uint32_t)(conf->literal - 5) << 3) |
+                 ((uint32_t)(conf->use_custom_dictionary != 0) << 2) | ((uint32_t)(conf->extended != 0) << 1) |
+                 (uint32_t)(conf->dictionary_reset != 0);
+    *nbits = conf->dictionary_reset ? 16 : 8;
+    return conf->dictionary_reset ? h << 8 : h;
+}
+
+int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *in, size_t n, uint8_t *out,
+                    size_t cap, size_t *out_len) {
+    if (out_len) *out_len = 0;
+    if (conf->window < 8 || conf->window > 15) return ORACLE_INVALID_CONF; /* compressor.c:208-209 */
+    if (conf->literal < 5 || conf->literal > 8) return ORACLE_INVALID_CONF;
+    if (conf->use_custom_dictionary && !dict) return ORACLE_INVALID_CONF;
+    uint8_t win[1 << 15];
+    const uint32_t W = 1u << conf->window;
+    if (conf->use_custom_dictionary)
+        memcpy(win, dict, W);
+    else
+        oracle_initialize_dictionary(win, W, conf->extended ? conf->literal : 8); /* compressor.c:224-225 */
+    unsigned hb;
+    uint32_t h = header_bits(conf, &hb), wp = 0;
+    return compress_core(conf, win, &wp, h, hb, in, n, out, cap, out_len, 0, NULL);
+}
+
+int oracle_compress_segment(const OracleConf *conf, int emit_header, int append_marker, int resume, int flush_token,
+                            uint8_t *window_state, uint16_t *window_pos, const uint8_t *in, size_t n, uint8_t *out,
+                            size_t cap, size_t *out_len, int *token_written) {
+    if (out_len) *out_len = 0;
+    if (conf->window < 8 || conf->window > 15) return ORACLE_INVALID_CONF;
+    if (conf->literal < 5 || conf->literal > 8) return ORACLE_INVALID_CONF;
+    const uint32_t W = 1u << conf->window;
+    uint32_t wp = *window_pos;
+    if (!resume) {
+        wp = 0;
+        if (!conf->use_custom_dictionary)
+            oracle_initialize_dictionary(window_state, W, conf->extended ? conf->literal : 8);
+    }
+    uint32_t lead = 0;
+    unsigned lead_bits = 0;
+    if (append_marker) /* compressor.c:227-235: FLUSH padded to 16 bits */
+        lead = (uint32_t)k_code[SYM_FLUSH] << 7, lead_bits = 16;
+    else if (emit_header)
+        lead = header_bits(conf, &lead_bits);
+    int res = compress_core(conf, window_state, &wp, lead, lead_bits, in, n, out, cap, out_len, flush_token,
+                            token_written);
+    *window_pos = (uint16_t)wp;
+    return res;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -67,6 +67,18 @@ int oracle_compress(const OracleConf *conf, const uint8_t *dict, const uint8_t *
                     size_t cap, size_t *out_len);
 
 /*
+ * One SEGMENT of a stream (streaming surface, tamp/_c_compressor.pyx:70-170): the bytes the reference emits for
+ *   [tamp_compressor_init: header (emit_header) or append marker (append_marker), compressor.c:227-241]
+ *   tamp_compressor_compress(in, n) ... tamp_compressor_flush(write_token = flush_token)   (compressor.c:728-810)
+ * with the window carried in window_state / *window_pos (ring order, like TampCompressor.window/window_pos).
+ * resume = 0 seeds a fresh window (or takes the custom dictionary already in window_state).  The caller folds the
+ * reference's last_was_flush rule (compressor.c:784) into flush_token; *token_written reports the outcome.
+ */
+int oracle_compress_segment(const OracleConf *conf, int emit_header, int append_marker, int resume, int flush_token,
+                            uint8_t *window_state, uint16_t *window_pos, const uint8_t *in, size_t n, uint8_t *out,
+                            size_t cap, size_t *out_len, int *token_written);
+
+/*
  * One stream, one shot: same bytes and same status as
  *   tamp_decompressor_init(&d, NULL, window, max_window_bits)     (decompressor.c:331-347)
  *   tamp_decompressor_decompress(&d, out, cap, &w, in, n, &consumed)   (decompressor.c:371-578)

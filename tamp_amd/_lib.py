@@ -28,6 +28,7 @@ SYMBOLS = (
     "tamp_batch_decompress",
     "tamp_amd_compress",
     "tamp_amd_decompress",
+    "tamp_amd_compress_segment",
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
@@ -99,6 +100,9 @@ def load() -> C.CDLL:
     lib.tamp_amd_compress.restype = C.c_int8
     lib.tamp_amd_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz), i32]
     lib.tamp_amd_decompress.restype = C.c_int8
+    lib.tamp_amd_compress_segment.argtypes = [C.POINTER(TampAmdConf), i32, i32, i32, i32, vp, C.POINTER(C.c_uint16), vp, sz,
+                                              C.POINTER(sz), vp, sz, C.POINTER(i32), i32]
+    lib.tamp_amd_compress_segment.restype = C.c_int8
     lib.tamp_amd_read_header.argtypes = [C.POINTER(TampAmdConf), vp, sz, C.POINTER(sz)]
     lib.tamp_amd_read_header.restype = C.c_int8
     lib.tamp_amd_set_timing.argtypes = [i32]

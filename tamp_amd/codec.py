@@ -3,9 +3,9 @@
 Same names, keyword arguments and exception mapping (``tamp/_c_common.pyx:6-16``).  The codec work of every
 call goes through the C ABI as a batch of one stream on the GPU; nothing is computed on the host.
 
-Scope in this release (SURVEY.md section 8f row 2 is "next"): a ``Compressor`` produces ONE segment -- data is
-gathered by ``write()`` and encoded by ``flush(write_token=False)`` / ``close()``; mid-stream FLUSH tokens,
-``dictionary_reset`` / ``append`` are rejected with ``NotImplementedError`` rather than emulated on the CPU.
+The streaming ``Compressor`` encodes one segment per flush point with the window
+carried across calls on the host side of the C ABI; FLUSH tokens, ``dictionary_reset``, ``append`` and
+``reset_dictionary()`` are produced by the kernel, not emulated on the CPU.
 """
 from __future__ import annotations
 
@@ -43,7 +43,13 @@ def _raise_for(res: int):
 
 
 class Compressor:
-    """``tamp.Compressor`` (tamp/_c_compressor.pyx:13-186)."""
+    """``tamp.Compressor`` (tamp/_c_compressor.pyx:13-186) over the segment call of the engine.
+
+    ``write()`` gathers bytes; every ``flush()`` / ``reset_dictionary()`` / ``close()`` encodes what was gathered as
+    one SEGMENT on the GPU (``tamp_amd_compress_segment``), with the window carried from segment to segment in
+    ``_window`` / ``_window_pos`` exactly as ``TampCompressor.window`` / ``window_pos`` carry it.  The bytes that reach
+    ``f`` are the reference's; they reach it at flush points rather than during ``write()``, so ``write()`` returns 0.
+    """
 
     def __init__(self, f, *, window: int = 10, literal: int = 8, dictionary=None, lazy_matching: bool = False,
                  extended: bool = True, dictionary_reset: bool = False, append: bool = False, device: int = 0):
@@ -51,49 +57,79 @@ class Compressor:
             raise ValueError("Dictionary-window size mismatch.")
         if not (8 <= window <= 15 and 5 <= literal <= 8):
             raise ValueError  # tamp_compressor_init -> TAMP_INVALID_CONF -> ValueError
-        if dictionary_reset or append:
-            raise NotImplementedError("dictionary_reset / append: SURVEY.md section 8f row 2 (next)")
+        if append and (not dictionary_reset or dictionary is not None):
+            raise ValueError  # compressor.c:209
         if not hasattr(f, "write"):
             f = builtins.open(str(f), "wb")
             self._close_f_on_close = True
         else:
             self._close_f_on_close = False
         self.f = f
-        self._conf = TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), 0,
-                                 int(bool(lazy_matching)))
-        self._dictionary = bytes(dictionary) if dictionary is not None else None
-        self._dictionary_reset = dictionary_reset
+        self._conf = TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)),
+                                 int(bool(dictionary_reset)), int(bool(lazy_matching)))
+        self._dictionary_reset = bool(dictionary_reset)
+        self._append = bool(append)
+        self._window = (C.c_ubyte * (1 << window))()
+        if dictionary is not None:
+            self._window[:] = bytes(dictionary)
+        self._window_pos = C.c_uint16(0)
         self._pending = bytearray()
-        self._emitted = False
+        self._opened = False    # header / append marker already sent
+        self._resume = False    # _window holds a carried window (else: fresh stream)
+        self._last_was_flush = self._append  # compressor.c:234
         self._device = device
         _lib.load()  # fail loudly now if the native library is missing
 
     def write(self, data) -> int:
-        if self._emitted:
-            raise NotImplementedError("writing after a flush needs window carry-over: SURVEY.md section 8f row 2")
         self._pending += bytes(data)
         return 0
 
-    def flush(self, write_token: bool = True) -> int:
-        if write_token:
-            raise NotImplementedError("mid-stream FLUSH token: SURVEY.md section 8f row 2 (next)")
-        if self._emitted:
-            return 0
+    def _segment(self, flush_token: bool) -> int:
         lib = _lib.load()
         n = len(self._pending)
-        cap = lib.tamp_amd_compress_bound(n, self._conf.literal, 0)
+        if n:
+            self._last_was_flush = False  # compressor.c:548
+        want_token = bool(flush_token) and not self._last_was_flush  # compressor.c:784
+        if n == 0 and self._opened and not (want_token and self._dictionary_reset):
+            return 0  # byte aligned, nothing buffered: the reference's flush writes nothing either
+        cap = lib.tamp_amd_compress_bound(n, self._conf.literal, 0) + 4
         out = (C.c_ubyte * cap)()
         written = C.c_size_t(0)
+        token = C.c_int(0)
         src = (C.c_ubyte * max(n, 1)).from_buffer_copy(bytes(self._pending) if n else b"\0")
-        d = (C.c_ubyte * len(self._dictionary)).from_buffer_copy(self._dictionary) if self._dictionary else None
-        res = lib.tamp_amd_compress(C.byref(self._conf), d, out, cap, C.byref(written), src, n, self._device)
+        res = lib.tamp_amd_compress_segment(
+            C.byref(self._conf), int(not self._opened and not self._append), int(not self._opened and self._append),
+            int(self._resume), int(want_token), self._window, C.byref(self._window_pos), out, cap,
+            C.byref(written), src, n, C.byref(token), self._device)
         if res < 0:
             _raise_for(res)
-        self._emitted = True
+        self._opened = self._resume = True
         self._pending.clear()
-        self.f.write(bytes(out[: written.value]))
-        self.f.flush()
+        if token.value:
+            self._last_was_flush = True
+        if written.value:
+            self.f.write(bytes(out[: written.value]))
         return written.value
+
+    def flush(self, write_token: bool = True) -> int:
+        n = self._segment(write_token)
+        self.f.flush()
+        return n
+
+    def reset_dictionary(self) -> int:
+        """``tamp_compressor_reset_dictionary`` (compressor.c:845-881): double FLUSH, then a fresh seeded window."""
+        if not self._dictionary_reset:
+            raise ValueError  # TAMP_INVALID_CONF
+        total = 0
+        for _ in range(2):
+            self._last_was_flush = False
+            total += self._segment(True)
+        self._resume = False  # next segment starts from the seed dictionary again (never the custom one)
+        self._conf.use_custom_dictionary = 0
+        self._window_pos = C.c_uint16(0)
+        self._last_was_flush = self._append
+        self.f.flush()
+        return total
 
     def close(self) -> int:
         bytes_written = self.flush(write_token=self._dictionary_reset)

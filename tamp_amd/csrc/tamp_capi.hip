@@ -128,6 +128,12 @@ void timing_end(hipStream_t st) {
     t_ev_valid = true;
 }
 
+struct SegmentSpec {  // streaming Compressor over the engine: how this piece of the stream opens and closes
+    uint8_t nlead;
+    uint16_t lead;
+    uint8_t flags;  // kSegResume | kSegSave | kSegFlushToken
+};
+
 uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
     // positions matched per epoch: the whole stream when it is short, else 2048 (LDS ~30 KB at W=1024,
     // five workgroups per CU); always a multiple of 64 (the walk chases 64 positions per register)
@@ -142,7 +148,7 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
 int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
                     const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                     const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, size_t n_streams,
-                    uint32_t max_in_len, hipStream_t st) {
+                    uint32_t max_in_len, hipStream_t st, const SegmentSpec* seg = nullptr, uint8_t* d_state = nullptr) {
     if (n_streams == 0) return TAMP_OK;
     CompressArgs a;
     a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
@@ -150,10 +156,17 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.wbits = conf->window, a.lbits = conf->literal, a.extended = conf->extended != 0;
     a.dict_reset = conf->dictionary_reset != 0;
     a.lazy = conf->lazy_matching != 0;
-    // header byte, compressor.c:236-241
-    a.header = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) |
-                         ((conf->use_custom_dictionary != 0) << 2) | ((conf->extended != 0) << 1) |
-                         (conf->dictionary_reset != 0));
+    // header byte, compressor.c:236-241 (+ a zero second byte when dictionary_reset is set)
+    const uint8_t header = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) |
+                                     ((conf->use_custom_dictionary != 0) << 2) | ((conf->extended != 0) << 1) |
+                                     (conf->dictionary_reset != 0));
+    a.nlead = conf->dictionary_reset ? 2 : 1;
+    a.lead = (uint16_t)(header << 8);
+    a.seg_flags = 0;
+    a.state = nullptr;
+    if (seg) {
+        a.nlead = seg->nlead, a.lead = seg->lead, a.seg_flags = seg->flags, a.state = d_state;
+    }
     if (conf->use_custom_dictionary) {
         a.dict = d_dict;
     } else {
@@ -676,6 +689,84 @@ tamp_res tamp_decompressor_decompress(TampDecompressor* decompressor, unsigned c
                                       size_t* input_consumed_size) {
     return tamp_decompressor_decompress_cb(decompressor, output, output_size, output_written_size, input, input_size,
                                            input_consumed_size, nullptr, nullptr);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Segment call: one piece of a stream between two flush points, with the window carried in and out.
+// This is what tamp.Compressor.write()/flush()/reset_dictionary() need (compressor.c:227-241,728-881).
+// ---------------------------------------------------------------------------------------------
+tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int append_marker, int resume,
+                                   int flush_token, unsigned char* window_state, uint16_t* window_pos,
+                                   unsigned char* output, size_t output_size, size_t* output_written_size,
+                                   const unsigned char* input, size_t input_size, int* token_written, int device) {
+    if (output_written_size) *output_written_size = 0;
+    if (token_written) *token_written = 0;
+    if (!conf_valid(conf) || conf->lazy_matching > 1 || !window_state || !window_pos) return TAMP_INVALID_CONF;
+    if (input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return (tamp_res)rc;
+    const size_t W = (size_t)1 << conf->window;
+    SegmentSpec seg;
+    seg.flags = kSegSave | (resume ? kSegResume : 0) | (flush_token ? kSegFlushToken : 0);
+    if (append_marker) {  // compressor.c:227-235: FLUSH (9 bits) padded to 16 bits instead of a header
+        seg.nlead = 2, seg.lead = (uint16_t)(0xABu << 7);
+    } else if (emit_header) {
+        const uint8_t header = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) |
+                                         ((conf->use_custom_dictionary != 0) << 2) | ((conf->extended != 0) << 1) |
+                                         (conf->dictionary_reset != 0));
+        seg.nlead = conf->dictionary_reset ? 2 : 1, seg.lead = (uint16_t)(header << 8);
+    } else {
+        seg.nlead = 0, seg.lead = 0;
+    }
+    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_state, d_dict;
+    const uint64_t zero = 0;
+    const uint32_t ilen = (uint32_t)input_size;
+    const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+    HIP_OK(d_in.alloc(input_size + 64));
+    HIP_OK(d_out.alloc(output_size));
+    HIP_OK(d_io.alloc(8));
+    HIP_OK(d_il.alloc(4));
+    HIP_OK(d_oo.alloc(8));
+    HIP_OK(d_oc.alloc(4));
+    HIP_OK(d_ol.alloc(4));
+    HIP_OK(d_st.alloc(1));
+    HIP_OK(d_state.alloc(W + 4));
+    std::vector<unsigned char> stbuf(W + 4, 0);
+    std::memcpy(stbuf.data(), window_state, W);
+    stbuf[W] = (unsigned char)(*window_pos & 0xFF), stbuf[W + 1] = (unsigned char)(*window_pos >> 8);
+    hipStream_t st = nullptr;
+    if (input_size) HIP_OK(hipMemcpyAsync(d_in.p, input, input_size, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_io.p, &zero, 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_il.p, &ilen, 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oo.p, &zero, 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oc.p, &ocap, 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_state.p, stbuf.data(), W + 4, hipMemcpyHostToDevice, st));
+    const uint8_t* dict = nullptr;
+    if (!resume && conf->use_custom_dictionary) {  // a fresh stream with a custom dictionary: the state buffer holds it
+        HIP_OK(d_dict.alloc(W));
+        HIP_OK(hipMemcpyAsync(d_dict.p, window_state, W, hipMemcpyHostToDevice, st));
+        dict = d_dict.as<uint8_t>();
+    }
+    rc = launch_compress(ctx, conf, dict, d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(),
+                         d_out.as<uint8_t>(), d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(),
+                         d_st.as<int8_t>(), 1, ilen ? ilen : 16, st, &seg, d_state.as<uint8_t>());
+    if (rc != TAMP_OK) return (tamp_res)rc;
+    uint32_t olen = 0;
+    int8_t status = TAMP_ERROR;
+    HIP_OK(hipMemcpyAsync(&olen, d_ol.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&status, d_st.p, 1, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(stbuf.data(), d_state.p, W + 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (olen) HIP_OK(hipMemcpy(output, d_out.p, olen, hipMemcpyDeviceToHost));
+    if (output_written_size) *output_written_size = olen;
+    if (status == TAMP_OK) {
+        std::memcpy(window_state, stbuf.data(), W);
+        *window_pos = (uint16_t)(stbuf[W] | (stbuf[W + 1] << 8));
+        if (token_written) *token_written = stbuf[W + 2];
+    }
+    return status;
 }
 
 }  // extern "C"

@@ -47,7 +47,13 @@ struct CompressArgs {
     const uint8_t* dict;  // 1<<wbits bytes: the custom dictionary or the seeded default
     uint32_t n_streams;
     uint32_t blk;  // epoch block: positions matched per epoch (multiple of 64)
-    uint8_t wbits, lbits, extended, header, dict_reset, lazy;
+    uint8_t wbits, lbits, extended, dict_reset, lazy;
+    // Segment mode (streaming Compressor over the engine, compressor.c:227-241,728-810): what opens the output, what
+    // closes it, and an optional per-stream window state that is read at the start and written back at the end.
+    uint8_t nlead;      // leading bytes 0..2: header (+ zero byte with dictionary_reset), FLUSH+pad when appending, none when resuming
+    uint16_t lead;      // those bytes, first one in the high byte
+    uint8_t seg_flags;  // kSegResume | kSegSave | kSegFlushToken
+    uint8_t* state;     // per stream: (1 << wbits) window bytes in ring order, then u16 window_pos, then u8 token-written flag
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
 };
@@ -438,6 +444,7 @@ struct Walk {
 };
 
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
+enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
 // ctl words
 enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8 };
 
@@ -502,29 +509,35 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         uint8_t* const gout = a.out + a.out_off[s];
         const uint32_t cap = a.out_cap[s];
 
-        // window <- dictionary (custom, or the seeded default prepared by the host shim)
-        if ((reinterpret_cast<uintptr_t>(a.dict) & 3) == 0) {
+        uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + 4) : nullptr;
+        uint32_t wp0 = 0;
+        if (st_io && (a.seg_flags & kSegResume)) {
+            // window <- saved state (ring order) rotated so that the oldest byte comes first
+            wp0 = (uint32_t)st_io[W] | ((uint32_t)st_io[W + 1] << 8);
+            for (uint32_t k = tid; k < W; k += nt) ebuf[k] = st_io[(wp0 + k) & mask];
+        } else if ((reinterpret_cast<uintptr_t>(a.dict) & 3) == 0) {
+            // window <- dictionary (custom, or the seeded default prepared by the host shim)
             for (uint32_t k = tid * 4; k < W; k += nt * 4)
                 *reinterpret_cast<uint32_t*>(ebuf + k) = *reinterpret_cast<const uint32_t*>(a.dict + k);
         } else {
             for (uint32_t k = tid; k < W; k += nt) ebuf[k] = a.dict[k];
         }
-        // bit buffer: header byte(s) (compressor.c:236-241), rest zero
+        // bit buffer: leading bytes (header, compressor.c:236-241; FLUSH + pad when appending, :227-235), rest zero
         for (uint32_t k = tid; k < L.obuf_words; k += nt)
-            obuf[k] = k == 0 ? __builtin_bswap32((uint32_t)a.header << 24) : 0;
+            obuf[k] = k == 0 ? __builtin_bswap32((uint32_t)a.lead << 16) : 0;
 
         Walk wk;
         wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
-        wk.wp_e = 0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
+        wk.wp_e = wp0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
         wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
         // workgroup-uniform output state
-        uint32_t carry = a.dict_reset ? 16u : 8u;  // bits already sitting in obuf (header; a second byte is zero)
+        uint32_t carry = 8u * a.nlead;  // bits already sitting in obuf
         uint32_t gpos = 0;                         // bytes already flushed to HBM
-        uint32_t e_p0 = 0, e_pending = 0, e_wp = 0;  // epoch parameters
+        uint32_t e_p0 = 0, e_pending = 0, e_wp = wp0;  // epoch parameters
         bool need_match = true;
         // Positions matched per epoch.  A token that breaks the speculation throws the rest of the block away, so
         // after such a break the next block is small (data with long runs / window-end truncations tends to break
@@ -904,6 +917,13 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     } else if (ext && wk.ext_count) {  // compressor.c:764-766
                         wk.emit_ext();
                     } else {
+                        if (st_io && (a.seg_flags & kSegSave)) {  // hand the window back in ring order
+                            for (uint32_t i = lane; i < W; i += kWave) st_io[i] = (uint8_t)wk.win_l(i);
+                            if (lane == 0) {
+                                st_io[W] = (uint8_t)wk.wp();
+                                st_io[W + 1] = (uint8_t)(wk.wp() >> 8);
+                            }
+                        }
                         act = kActDone;
                         break;
                     }
@@ -1019,8 +1039,25 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 }
             }
             __syncthreads();
-            const uint32_t tot = carry + segbits;  // bits now in obuf
+            uint32_t tot = carry + segbits;  // bits now in obuf
             if (excess) act = kActDone;
+            if (act == kActDone && !excess && (a.seg_flags & kSegFlushToken)) {
+                // compressor.c:784-794: FLUSH (9 bits) only if bits are pending or the stream allows dictionary resets
+                const bool want = (tot & 7) != 0 || a.dict_reset;
+                if (want && tid == 0) {
+                    const uint32_t wi = tot >> 5, ph = tot & 31, v = 0xABu;
+                    if (ph + 9 <= 32) {
+                        obuf[wi] |= __builtin_bswap32(v << (32 - ph - 9));
+                    } else {
+                        const uint32_t hi = 32 - ph;
+                        obuf[wi] |= __builtin_bswap32(v >> (9 - hi));
+                        obuf[wi + 1] |= __builtin_bswap32((v & ((1u << (9 - hi)) - 1)) << (32 - (9 - hi)));
+                    }
+                }
+                if (want) tot += 9;
+                if (st_io && tid == 0) st_io[W + 2] = want ? 1 : 0;
+                __syncthreads();
+            }
             // flush whole words (or, at the end, the zero-padded / truncated byte count) to HBM
             uint32_t nbytes;
             if (act == kActDone)

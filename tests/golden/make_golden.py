@@ -11,6 +11,8 @@ Two kinds of fixture are written:
   inputs (tamp_amd/workloads.py), one record per (workload, stream, configuration): SHA-256 of
   the input, the compressed bytes (base64) and the decode status/size.
 * ``dictionaries.json`` -- tamp_initialize_dictionary for every (size, literal) pair.
+* ``streaming.json`` -- op scripts (write / flush / reset_dictionary / close) replayed on one reference
+  compressor object, with the bytes it emitted.
 * ``device_vectors.json`` -- the reference's malformed/valid decoder vectors
   (devices/vectors/*.bin, data files its own tests replay) with the status/output the reference
   decoder produces for them.
@@ -190,6 +192,92 @@ def device_vectors(ref: Ref):
     return recs
 
 
+def streaming(ref: Ref):
+    """Op scripts on ONE reference compressor object: the shapes of tests/test_compressor_decompressor.py:312-556
+    (reset_dictionary_*, append_mode_roundtrip, double_flush_does_not_reset) on this repo's synthetic text, plus
+    seeded random scripts.  ``expected`` is what the reference wrote; ``decodes`` says whether the reference decoder
+    turns it back into the concatenated writes (not the case when a write_token=False flush pads mid-stream)."""
+    import random
+
+    text = bytes(wl.synth_text(1, 6000, first_index=77)[0])
+    runs = bytes(wl.lcg_runs(1, 3000, first_index=5)[0])
+    hello, bye = b"Hello world! " * 20, b"Goodbye world! " * 20
+    W, F, R, CL = (lambda b: ("write", b)), (lambda t: ("flush", t)), ("reset",), ("close",)
+    scripts = [
+        ("reset_dictionary_basic", ":312-327", dict(dictionary_reset=True),
+         [W(text[:200]), F(True), R, W(text[200:3000]), F(False)]),
+        ("reset_dictionary_no_prior_flush", ":329-345", dict(dictionary_reset=True), [W(hello), R, W(bye), F(False)]),
+        ("reset_dictionary_multiple", ":347-366", dict(dictionary_reset=True),
+         [W(text[:500]), R, W(text[500:1000]), R, W(text[1000:1500]), F(False)]),
+        ("reset_dictionary_immediate", ":368-382", dict(dictionary_reset=True), [R, W(text[:800]), F(False)]),
+        ("reset_dictionary_v1", ":384-399", dict(dictionary_reset=True, extended=False),
+         [W(text[:300]), F(True), R, W(text[300:900]), F(False)]),
+        ("reset_dictionary_lazy", ":401-418", dict(dictionary_reset=True, lazy_matching=True),
+         [W(text[:300]), F(True), R, W(text[300:900]), F(False)]),
+        ("reset_dictionary_small_window", ":420-436", dict(dictionary_reset=True, window=8),
+         [W(text[:700]), R, W(text[700:1400]), F(False)]),
+        ("reset_dictionary_literal7", ":438-456", dict(dictionary_reset=True, literal=7),
+         [W(text[:700]), R, W(text[700:1400]), F(False)]),
+        ("reset_dictionary_rle_boundary", ":458-474", dict(dictionary_reset=True),
+         [W(b"A" * 100), R, W(b"A" * 100 + b"B" * 50), F(False)]),
+        ("append_session_1", ":510-530", dict(dictionary_reset=True), [W(hello[:39]), CL]),
+        ("append_session_2", ":510-530", dict(dictionary_reset=True, append=True), [W(bye[:45]), CL]),
+        ("double_flush_does_not_reset", ":532-555", dict(dictionary_reset=True),
+         [W(hello), F(True), F(True), F(True), W(bye), F(False)]),
+        ("flush_tokens_no_reset_conf", "tests/test_compressor.py:241-246 (flush() default)", dict(),
+         [W(text[:100]), F(True), W(text[100:117]), F(True), F(True), W(text[117:1000]), CL]),
+        ("split_writes_equal_one_shot", "tamp/_c_compressor.pyx:70-116", dict(),
+         [W(text[i : i + 37]) for i in range(0, 3000, 37)] + [F(False)]),
+        ("rle_across_flush", "compressor.c:745-762", dict(), [W(runs[:777]), F(True), W(runs[777:2000]), F(True), CL]),
+        ("empty_stream_close", "compressor.c:784", dict(), [CL]),
+        ("empty_stream_close_reset_conf", "compressor.c:784", dict(dictionary_reset=True), [CL]),
+        ("custom_dictionary_then_reset", "compressor.c:871-873", dict(dictionary_reset=True, window=9,
+                                                                      dictionary=text[4000:4512]),
+         [W(text[4100:4600]), R, W(text[4100:4600]), CL]),
+    ]
+    rng = random.Random(20260928)
+    srcs = [text, runs, bytes(wl.stress(3, 4096)[1]), bytes(wl.stress(3, 4096)[2])]
+    for k in range(48):
+        src = rng.choice(srcs)
+        dr = rng.random() < 0.5
+        conf = dict(window=rng.choice([8, 9, 10, 11, 12, 15]), literal=8, extended=rng.random() < 0.7,
+                    dictionary_reset=dr, append=dr and rng.random() < 0.2, lazy_matching=rng.random() < 0.25)
+        pos, ops = rng.randrange(0, 1000), []
+        for _ in range(rng.randrange(2, 9)):
+            x = rng.random()
+            if x < 0.55:
+                n = rng.choice([0, 1, 2, 3, 15, 16, 17, 31, 40, 100, 300, 700])
+                ops.append(W(src[pos : pos + n]))
+                pos += n
+            elif x < 0.85:
+                ops.append(F(rng.random() < 0.7))
+            elif dr:
+                ops.append(R)
+        ops.append(CL)
+        scripts.append((f"random_{k:02d}", "seeded script", conf, ops))
+    recs = []
+    for name, cite, conf, ops in scripts:
+        if cite.startswith(":"):
+            cite = "tests/test_compressor_decompressor.py" + cite
+        st, got = ref.stream_script(ops, **conf)
+        plain = b"".join(op[1] for op in ops if op[0] == "write")
+        decodes = False
+        if st == 0 and not conf.get("append"):
+            dst, back, _ = ref.decompress(got, dictionary=conf.get("dictionary"), cap=len(plain) + 64)
+            decodes = dst == 2 and back == plain
+        jconf = {k: (b64(v) if k == "dictionary" else v) for k, v in conf.items()}
+        recs.append(dict(name=name, cite=cite, conf=jconf, status=st, expected=b64(got), decodes=decodes,
+                         plain_sha256=sha(plain),
+                         ops=[[op[0], b64(op[1])] if op[0] == "write" else list(op) for op in ops]))
+    s1 = next(r for r in recs if r["name"] == "append_session_1")
+    s2 = next(r for r in recs if r["name"] == "append_session_2")
+    cat = base64.b64decode(s1["expected"]) + base64.b64decode(s2["expected"])
+    dst, back, _ = ref.decompress(cat, cap=4096)
+    assert dst == 2 and back == hello[:39] + bye[:45], (dst, back)
+    assert sum(r["decodes"] for r in recs) > 20
+    return recs
+
+
 def main():
     ref = Ref()
     assert ref.sizes() == (2, 48, 24), ref.sizes()
@@ -198,6 +286,7 @@ def main():
         ("dictionaries.json", dictionaries(ref)),
         ("generated.json", generated(ref)),
         ("device_vectors.json", device_vectors(ref)),
+        ("streaming.json", streaming(ref)),
     ):
         with open(os.path.join(HERE, fname), "w") as f:
             json.dump(obj, f, indent=0, sort_keys=True)

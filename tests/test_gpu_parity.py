@@ -241,6 +241,86 @@ def test_long_single_stream(ta, oracle):
         assert ta.decompress(want) == data
 
 
+def _replay(ta, ops, conf):
+    import io
+
+    f = io.BytesIO()
+    c = ta.Compressor(f, **conf)
+    for op in ops:
+        if op[0] == "write":
+            c.write(op[1])
+        elif op[0] == "flush":
+            c.flush(write_token=bool(op[1]))
+        elif op[0] == "reset":
+            c.reset_dictionary()
+        elif op[0] == "close":
+            c.close()
+    return f.getvalue()
+
+
+def test_streaming_scripts_golden(ta):
+    """tamp_amd.Compressor driven like tests/test_compressor_decompressor.py:312-556 drives tamp.Compressor:
+    every byte that reaches the file equals what the reference object wrote (tests/golden/streaming.json)."""
+    recs = load_golden("streaming.json")
+    sessions = {}
+    for rec in recs:
+        conf = dict(rec["conf"])
+        if "dictionary" in conf:
+            conf["dictionary"] = unb64(conf["dictionary"])
+        ops = [("write", unb64(op[1])) if op[0] == "write" else tuple(op) for op in rec["ops"]]
+        assert rec["status"] == 0
+        got = _replay(ta, ops, conf)
+        assert got == unb64(rec["expected"]), (rec["name"], rec["cite"])
+        sessions[rec["name"]] = (got, b"".join(op[1] for op in ops if op[0] == "write"))
+        if rec["decodes"]:
+            back = ta.decompress(got, dictionary=conf.get("dictionary"))
+            assert hashlib.sha256(bytes(back)).hexdigest() == rec["plain_sha256"], rec["name"]
+    # append mode: two sessions concatenated decode as one stream (test_append_mode_roundtrip, :510-530)
+    (a, pa), (b, pb) = sessions["append_session_1"], sessions["append_session_2"]
+    assert bytes(ta.decompress(a + b)) == pa + pb
+
+
+def test_streaming_differential_vs_oracle(ta, oracle):
+    from tamp_amd import workloads as wl
+
+    rng = random.Random(99)
+    srcs = [bytes(wl.synth_text(1, 20000, first_index=123)[0]), bytes(wl.lcg_runs(1, 8000, first_index=9)[0]),
+            bytes(wl.stress(3, 8192)[1]), bytes(wl.stress(3, 8192)[2]), b"\0" * 6000]
+    for k in range(60):
+        src = rng.choice(srcs)
+        dr = rng.random() < 0.5
+        conf = dict(window=rng.choice([8, 9, 10, 12, 15]), literal=8, extended=rng.random() < 0.7,
+                    dictionary_reset=dr, append=dr and rng.random() < 0.2, lazy_matching=rng.random() < 0.2)
+        pos, ops = rng.randrange(0, 2000), []
+        for _ in range(rng.randrange(1, 7)):
+            x = rng.random()
+            if x < 0.55:
+                n = rng.choice([0, 1, 2, 3, 15, 16, 17, 31, 100, 700, 3000])
+                ops.append(("write", src[pos : pos + n]))
+                pos += n
+            elif x < 0.85:
+                ops.append(("flush", rng.random() < 0.7))
+            elif dr:
+                ops.append(("reset",))
+        ops.append(("close",))
+        st, want = oracle.stream_script(ops, **conf)
+        assert st == 0
+        assert _replay(ta, ops, conf) == want, (k, conf, [(o[0], len(o[1]) if o[0] == "write" else o[1:]) for o in ops])
+
+
+def test_streaming_errors(ta):
+    import io
+
+    with pytest.raises(ValueError):
+        ta.Compressor(io.BytesIO(), append=True)  # append needs dictionary_reset (compressor.c:209)
+    with pytest.raises(ValueError):
+        ta.Compressor(io.BytesIO()).reset_dictionary()  # TAMP_INVALID_CONF (compressor.c:846)
+    c = ta.Compressor(io.BytesIO(), literal=7, extended=False)
+    c.write(b"\xff")
+    with pytest.raises(ta.ExcessBitsError):  # tests/test_compressor.py:239-246
+        c.flush()
+
+
 def test_reference_named_c_api(ta, oracle):
     """include/tamp_compat.h: the reference's own symbols (ctests/test_compressor.c round-trip shape) via ctypes."""
     import ctypes as C

@@ -65,8 +65,12 @@ def test_surface_argument_errors_need_no_device():
         tamp_amd.Compressor(io.BytesIO(), window=16)
     with pytest.raises(ValueError):
         tamp_amd.open(io.BytesIO(), "rw")
-    with pytest.raises(NotImplementedError):
-        tamp_amd.Compressor(io.BytesIO(), dictionary_reset=True)
+    with pytest.raises(ValueError):  # append needs dictionary_reset and no custom dictionary (compressor.c:209)
+        tamp_amd.Compressor(io.BytesIO(), append=True)
+    with pytest.raises(ValueError):
+        tamp_amd.Compressor(io.BytesIO(), dictionary_reset=True, append=True, dictionary=bytearray(1024))
+    with pytest.raises(ValueError):  # tamp_compressor_reset_dictionary -> TAMP_INVALID_CONF (compressor.c:846)
+        tamp_amd.Compressor(io.BytesIO()).reset_dictionary()
     with pytest.raises(ValueError):
         tamp_amd.compress_batch([b"x"], window=8, dictionary=bytes(100))
 

@@ -86,6 +86,29 @@ def test_generated_reference_outputs(oracle):
     assert n_checked > 250
 
 
+def _script(rec):
+    conf = dict(rec["conf"])
+    if "dictionary" in conf:
+        conf["dictionary"] = unb64(conf["dictionary"])
+    ops = [("write", unb64(op[1])) if op[0] == "write" else tuple(op) for op in rec["ops"]]
+    return conf, ops
+
+
+def test_streaming_scripts(oracle):
+    """write / flush(write_token) / reset_dictionary / close sequences, bytes emitted by ONE reference object
+    (tests/golden/streaming.json; shapes of tests/test_compressor_decompressor.py:312-556)."""
+    recs = load_golden("streaming.json")
+    assert len(recs) >= 60
+    for rec in recs:
+        conf, ops = _script(rec)
+        st, got = oracle.stream_script(ops, **conf)
+        assert st == rec["status"], rec["name"]
+        assert got == unb64(rec["expected"]), (rec["name"], rec["cite"])
+        if rec["decodes"]:
+            dst, back, _ = oracle.decompress(got, dictionary=conf.get("dictionary"), cap=1 << 16)
+            assert dst == 2 and hashlib.sha256(back).hexdigest() == rec["plain_sha256"], rec["name"]
+
+
 def test_invalid_conf(oracle):
     # compressor.c:208-209, tests/test_compressor.py:420-433
     assert oracle.compress(b"x", window=7)[0] == -3
