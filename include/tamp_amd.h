@@ -28,6 +28,9 @@ enum {
     TAMP_EXCESS_BITS = -2,
     TAMP_INVALID_CONF = -3,
     TAMP_OOB = -4,
+    TAMP_IO_ERROR = -10, /* stream API, common.h:160-163 */
+    TAMP_READ_ERROR = -11,
+    TAMP_WRITE_ERROR = -12,
     /* library-level failures of this implementation (outside the reference's range) */
     TAMP_AMD_NO_DEVICE = -20, /* no HIP device / HIP runtime error: nothing was computed */
     TAMP_AMD_BAD_ARGUMENT = -21,

@@ -1,5 +1,5 @@
 /*
- * tamp_compat.h -- the reference's OWN C symbol names for the one-shot path, served by libtamp_amd.so.
+ * tamp_compat.h -- the reference's OWN C symbol names, served by libtamp_amd.so.
  *
  * Struct layouts and prototypes follow the reference headers (paths relative to its repository root):
  *   TampConf .................................. tamp/_c_src/tamp/common.h:170-182 (lazy_matching field present, as in
@@ -8,20 +8,31 @@
  *                                               only the `window` pointer is public, the rest is private here too
  *   tamp_compressor_init ...................... compressor.h:84
  *   tamp_compressor_compress_and_flush[_cb] ... compressor.h:259,280-286
+ *   tamp_compressor_flush ..................... compressor.h:193
+ *   tamp_compressor_reset_dictionary .......... compressor.h:217
+ *   tamp_compress_stream ...................... compressor.h:338
  *   tamp_decompressor_read_header ............. decompressor.h:67
  *   tamp_decompressor_init .................... decompressor.h:83
  *   tamp_decompressor_decompress[_cb] ......... decompressor.h:93,128
+ *   tamp_decompress_stream .................... decompressor.h:190
+ *   tamp_callback_t / tamp_read_t / tamp_write_t, TampMemReader/Writer, tamp_stream_{mem,stdio}_{read,write}
+ *                                               common.h:210-242,255-290 (host-only adaptors, common.c:92-132)
  *   tamp_initialize_dictionary, tamp_compute_min_pattern_size .... common.h:395,405 (declared in tamp_amd.h)
  *
- * Each call is a batch of one stream on HIP device $TAMP_AMD_DEVICE (default 0); there is no CPU code path.
- * What a compressor/decompressor object supports in this release is ONE whole-stream call after init:
- *   - tamp_compressor_compress_and_flush on a freshly initialised compressor, write_token = false
- *     (exactly what tamp.compress() and every reference benchmark do);
- *   - tamp_decompressor_decompress with the complete stream (conf read from the header, or passed to init with the
- *     input starting after the header, as tamp/_c_decompressor.pyx:50-75 does).
- * Anything that needs state carried between calls (sink / poll / flush with a FLUSH token / reset_dictionary / a
- * second compress or decompress call / the callback stream API) returns TAMP_ERROR instead of computing on the
- * host; that is SURVEY.md section 8(f) rows 2-3.  Progress callbacks are invoked once, at completion.
+ * Every codec call is a launch on HIP device $TAMP_AMD_DEVICE (default 0); there is no CPU code path.
+ *
+ * Compressor objects are stateful the way the reference's are at FLUSH granularity: the window lives in the
+ * caller's buffer, window_pos / last_was_flush in the object, and each tamp_compressor_compress_and_flush call
+ * (any write_token), tamp_compressor_flush, tamp_compressor_reset_dictionary or tamp_compress_stream encodes one
+ * segment on the device -- any number of them per object, bytes identical to the reference's.  What is NOT
+ * offered is the 16-byte ring interface below flush granularity (tamp_compressor_sink / _poll / _full and
+ * tamp_compressor_compress without a flush): there is no place in the 48-byte object to park unflushed input,
+ * and the library does not allocate on the caller's behalf ("no heap use").
+ *
+ * Decompressor objects decode ONE complete stream per object (conf from the header, or passed to init with the
+ * input starting after the header, as tamp/_c_decompressor.pyx:50-75 does); a second call with more input
+ * returns TAMP_ERROR.  tamp_decompress_stream pulls the whole input first, so it has no such limit.
+ * Progress callbacks are invoked per pulled chunk (stream API) or once at completion.
  */
 #ifndef TAMP_COMPAT_H
 #define TAMP_COMPAT_H
@@ -57,6 +68,25 @@ typedef struct TampDecompressor {
 } TampDecompressor;
 
 typedef int (*tamp_callback_t)(void *user_data, size_t bytes_processed, size_t total_bytes);
+typedef int (*tamp_read_t)(void *handle, unsigned char *buffer, size_t size);        /* fread-like, <0 = error */
+typedef int (*tamp_write_t)(void *handle, const unsigned char *buffer, size_t size); /* fwrite-like, <0 = error */
+
+typedef struct TampMemReader {
+    const unsigned char *data;
+    size_t size;
+    size_t pos; /* initialise to 0 */
+} TampMemReader;
+
+typedef struct TampMemWriter {
+    unsigned char *data;
+    size_t capacity;
+    size_t pos; /* initialise to 0 */
+} TampMemWriter;
+
+int tamp_stream_mem_read(void *handle, unsigned char *buffer, size_t size);
+int tamp_stream_mem_write(void *handle, const unsigned char *buffer, size_t size);
+int tamp_stream_stdio_read(void *handle, unsigned char *buffer, size_t size);
+int tamp_stream_stdio_write(void *handle, const unsigned char *buffer, size_t size);
 
 tamp_res tamp_compressor_init(TampCompressor *compressor, const TampConf *conf, unsigned char *window);
 
@@ -68,6 +98,20 @@ tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor *compressor, unsig
 tamp_res tamp_compressor_compress_and_flush(TampCompressor *compressor, unsigned char *output, size_t output_size,
                                             size_t *output_written_size, const unsigned char *input, size_t input_size,
                                             size_t *input_consumed_size, bool write_token);
+
+tamp_res tamp_compressor_flush(TampCompressor *compressor, unsigned char *output, size_t output_size,
+                               size_t *output_written_size, bool write_token);
+
+tamp_res tamp_compressor_reset_dictionary(TampCompressor *compressor, unsigned char *output, size_t output_size,
+                                          size_t *output_written_size);
+
+tamp_res tamp_compress_stream(TampCompressor *compressor, tamp_read_t read_cb, void *read_handle,
+                              tamp_write_t write_cb, void *write_handle, size_t *input_consumed_size,
+                              size_t *output_written_size, tamp_callback_t callback, void *user_data);
+
+tamp_res tamp_decompress_stream(TampDecompressor *decompressor, tamp_read_t read_cb, void *read_handle,
+                                tamp_write_t write_cb, void *write_handle, size_t *input_consumed_size,
+                                size_t *output_written_size, tamp_callback_t callback, void *user_data);
 
 tamp_res tamp_decompressor_read_header(TampConf *conf, const unsigned char *input, size_t input_size,
                                        size_t *input_consumed_size);

@@ -32,10 +32,18 @@ SYMBOLS = (
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
-    # include/tamp_compat.h: the reference's own symbol names for the one-shot path
+    # include/tamp_compat.h: the reference's own symbol names
     "tamp_compressor_init",
     "tamp_compressor_compress_and_flush_cb",
     "tamp_compressor_compress_and_flush",
+    "tamp_compressor_flush",
+    "tamp_compressor_reset_dictionary",
+    "tamp_compress_stream",
+    "tamp_decompress_stream",
+    "tamp_stream_mem_read",
+    "tamp_stream_mem_write",
+    "tamp_stream_stdio_read",
+    "tamp_stream_stdio_write",
     "tamp_decompressor_read_header",
     "tamp_decompressor_init",
     "tamp_decompressor_decompress_cb",

@@ -6,6 +6,8 @@
 // CPU code path for it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -521,10 +523,12 @@ tamp_res tamp_amd_read_header(TampAmdConf* conf, const unsigned char* input, siz
 // The reference's own symbol names for the one-shot path (include/tamp_compat.h)
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct CompressorPriv {  // lives in TampCompressor::private_ (40 bytes)
+struct CompressorPriv {  // lives in TampCompressor::private_ (40 bytes); the window itself is the caller's buffer
     uint32_t magic;
     TampConf conf;
-    uint8_t used;
+    uint16_t window_pos;     // TampCompressor.window_pos (compressor.h:24)
+    uint8_t opened;          // header / append marker already emitted
+    uint8_t last_was_flush;  // compressor.h:26
 };
 struct DecompressorPriv {  // lives in TampDecompressor::private_ (16 bytes)
     uint32_t magic;
@@ -552,36 +556,51 @@ tamp_res tamp_compressor_init(TampCompressor* compressor, const TampConf* conf, 
     std::memset(compressor, 0, sizeof *compressor);
     compressor->window = window;
     CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
-    p->magic = kMagicC, p->conf = *conf, p->used = 0;
+    p->magic = kMagicC, p->conf = *conf, p->window_pos = 0, p->opened = 0;
+    p->last_was_flush = conf->append;  // compressor.c:234
     if (!conf->use_custom_dictionary)  // compressor.c:224-225
         seed_dictionary_host(window, (size_t)1 << conf->window, conf->extended ? conf->literal : 8);
     return TAMP_OK;
 }
 
-tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
-                                               size_t* output_written_size, const unsigned char* input,
-                                               size_t input_size, size_t* input_consumed_size, bool write_token,
-                                               tamp_callback_t callback, void* user_data) {
+namespace {
+// One segment of a compat compressor object: everything between two flush points, window in the caller's buffer.
+tamp_res compat_segment(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                        size_t* output_written_size, const unsigned char* input, size_t input_size,
+                        bool write_token) {
     if (output_written_size) *output_written_size = 0;
-    if (input_consumed_size) *input_consumed_size = 0;
     CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
     if (p->magic != kMagicC) return TAMP_ERROR;
-    if (p->used || write_token || p->conf.append) {
-        snprintf(t_last_error, sizeof t_last_error,
-                 "tamp_compressor_compress_and_flush: only one whole-stream call with write_token=false on a fresh "
-                 "compressor is supported (no state carry-over yet)");
-        return TAMP_ERROR;
-    }
+    if (input_size) p->last_was_flush = 0;                      // compressor.c:548
+    const bool want_token = write_token && !p->last_was_flush;  // compressor.c:784
+    if (input_size == 0 && p->opened && !(want_token && p->conf.dictionary_reset)) return TAMP_OK;
     TampAmdConf c;
     std::memset(&c, 0, sizeof c);
     c.window = p->conf.window, c.literal = p->conf.literal, c.extended = p->conf.extended;
     c.use_custom_dictionary = p->conf.use_custom_dictionary, c.dictionary_reset = p->conf.dictionary_reset;
     c.lazy_matching = p->conf.lazy_matching;
     size_t written = 0;
-    tamp_res r = tamp_amd_compress(&c, c.use_custom_dictionary ? compressor->window : nullptr, output, output_size,
-                                   &written, input, input_size, compat_device());
+    int token = 0;
+    uint16_t wp = p->window_pos;
+    // resume=1 always: tamp_compressor_init already seeded (or the caller filled) compressor->window, wp = 0
+    tamp_res r = tamp_amd_compress_segment(&c, !p->opened && !p->conf.append, !p->opened && p->conf.append, 1,
+                                           want_token, compressor->window, &wp, output, output_size, &written, input,
+                                           input_size, &token, compat_device());
     if (output_written_size) *output_written_size = written;
-    p->used = 1;
+    if (r == TAMP_OK) {
+        p->window_pos = wp, p->opened = 1;
+        if (token) p->last_was_flush = 1;
+    }
+    return r;
+}
+}  // namespace
+
+tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                               size_t* output_written_size, const unsigned char* input,
+                                               size_t input_size, size_t* input_consumed_size, bool write_token,
+                                               tamp_callback_t callback, void* user_data) {
+    if (input_consumed_size) *input_consumed_size = 0;
+    tamp_res r = compat_segment(compressor, output, output_size, output_written_size, input, input_size, write_token);
     if (r == TAMP_OK) {
         if (input_consumed_size) *input_consumed_size = input_size;
         if (callback) {  // final "100 %" callback, compressor.c:836-842
@@ -590,6 +609,143 @@ tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsig
         }
     }
     return r;
+}
+
+tamp_res tamp_compressor_flush(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                               size_t* output_written_size, bool write_token) {
+    return compat_segment(compressor, output, output_size, output_written_size, nullptr, 0, write_token);
+}
+
+tamp_res tamp_compressor_reset_dictionary(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                          size_t* output_written_size) {  // compressor.c:845-881
+    if (output_written_size) *output_written_size = 0;
+    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
+    if (p->magic != kMagicC) return TAMP_ERROR;
+    if (!p->conf.dictionary_reset) return TAMP_INVALID_CONF;
+    for (int i = 0; i < 2; i++) {
+        size_t w = 0;
+        p->last_was_flush = 0;
+        tamp_res r = compat_segment(compressor, output, output_size, &w, nullptr, 0, true);
+        if (output_written_size) *output_written_size += w;
+        if (r != TAMP_OK) return r;
+        output += w, output_size -= w;
+    }
+    p->conf.use_custom_dictionary = 0;
+    seed_dictionary_host(compressor->window, (size_t)1 << p->conf.window, p->conf.extended ? p->conf.literal : 8);
+    p->window_pos = 0;
+    p->last_was_flush = p->conf.append;
+    return TAMP_OK;
+}
+
+tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, void* read_handle,
+                              tamp_write_t write_cb, void* write_handle, size_t* input_consumed_size,
+                              size_t* output_written_size, tamp_callback_t callback, void* user_data) {
+    // compressor.c:891-955: pull until EOF, compress, flush(write_token=false).  Here the pull fills one host
+    // buffer and the whole input is one segment on the device.
+    if (input_consumed_size) *input_consumed_size = 0;
+    if (output_written_size) *output_written_size = 0;
+    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
+    if (p->magic != kMagicC) return TAMP_ERROR;
+    std::vector<unsigned char> in;
+    constexpr size_t kChunk = 1 << 16;
+    for (;;) {
+        const size_t at = in.size();
+        in.resize(at + kChunk);
+        int got = read_cb(read_handle, in.data() + at, kChunk);
+        if (got < 0) return TAMP_READ_ERROR;
+        in.resize(at + (size_t)got);
+        if (got == 0) break;
+        if (input_consumed_size) *input_consumed_size = in.size();
+        if (callback) {
+            int cb = callback(user_data, in.size(), 0);
+            if (cb) return (tamp_res)cb;
+        }
+    }
+    std::vector<unsigned char> out(tamp_amd_compress_bound(in.size(), p->conf.literal, p->conf.dictionary_reset) + 4);
+    size_t written = 0;
+    tamp_res r = compat_segment(compressor, out.data(), out.size(), &written, in.data(), in.size(), false);
+    if (r != TAMP_OK) return r;
+    for (size_t at = 0; at < written;) {
+        const size_t n = std::min(written - at, kChunk);
+        int w = write_cb(write_handle, out.data() + at, n);
+        if (w < 0 || (size_t)w != n) return TAMP_WRITE_ERROR;
+        at += n;
+        if (output_written_size) *output_written_size = at;
+    }
+    return TAMP_OK;
+}
+
+tamp_res tamp_decompress_stream(TampDecompressor* decompressor, tamp_read_t read_cb, void* read_handle,
+                                tamp_write_t write_cb, void* write_handle, size_t* input_consumed_size,
+                                size_t* output_written_size, tamp_callback_t callback, void* user_data) {
+    // decompressor.c:585-640: pull until EOF, decode, push.  One whole-stream decode on the device.
+    if (input_consumed_size) *input_consumed_size = 0;
+    if (output_written_size) *output_written_size = 0;
+    std::vector<unsigned char> in;
+    constexpr size_t kChunk = 1 << 16;
+    for (;;) {
+        const size_t at = in.size();
+        in.resize(at + kChunk);
+        int got = read_cb(read_handle, in.data() + at, kChunk);
+        if (got < 0) return TAMP_READ_ERROR;
+        in.resize(at + (size_t)got);
+        if (got == 0) break;
+        if (input_consumed_size) *input_consumed_size = in.size();
+        if (callback) {
+            int cb = callback(user_data, in.size(), 0);
+            if (cb) return (tamp_res)cb;
+        }
+    }
+    std::vector<unsigned char> out(std::max<size_t>(4096, in.size() * 8));
+    for (;;) {
+        TampDecompressor d = *decompressor;  // a retry with a larger buffer starts from the same object state
+        size_t written = 0, consumed = 0;
+        tamp_res r = tamp_decompressor_decompress_cb(&d, out.data(), out.size(), &written, in.data(), in.size(),
+                                                     &consumed, nullptr, nullptr);
+        if (r == TAMP_OUTPUT_FULL) {
+            out.resize(out.size() * 4);
+            continue;
+        }
+        *decompressor = d;
+        if (r < 0) return r;
+        for (size_t at = 0; at < written;) {
+            const size_t n = std::min(written - at, kChunk);
+            int w = write_cb(write_handle, out.data() + at, n);
+            if (w < 0 || (size_t)w != n) return TAMP_WRITE_ERROR;
+            at += n;
+            if (output_written_size) *output_written_size = at;
+        }
+        return TAMP_OK;
+    }
+}
+
+// Built-in I/O handlers (common.c:92-132): plain host adaptors, no codec work.
+int tamp_stream_mem_read(void* handle, unsigned char* buffer, size_t size) {
+    TampMemReader* r = static_cast<TampMemReader*>(handle);
+    const size_t n = std::min(std::min(size, r->size - r->pos), (size_t)INT_MAX);
+    std::memcpy(buffer, r->data + r->pos, n);
+    r->pos += n;
+    return (int)n;
+}
+
+int tamp_stream_mem_write(void* handle, const unsigned char* buffer, size_t size) {
+    TampMemWriter* w = static_cast<TampMemWriter*>(handle);
+    if (size > w->capacity - w->pos || size > (size_t)INT_MAX) return -1;
+    std::memcpy(w->data + w->pos, buffer, size);
+    w->pos += size;
+    return (int)size;
+}
+
+int tamp_stream_stdio_read(void* handle, unsigned char* buffer, size_t size) {
+    FILE* f = static_cast<FILE*>(handle);
+    const size_t n = fread(buffer, 1, std::min(size, (size_t)INT_MAX), f);
+    return n == 0 && ferror(f) ? -1 : (int)n;
+}
+
+int tamp_stream_stdio_write(void* handle, const unsigned char* buffer, size_t size) {
+    FILE* f = static_cast<FILE*>(handle);
+    const size_t n = fwrite(buffer, 1, size, f);
+    return n < size && ferror(f) ? -1 : (int)n;
 }
 
 tamp_res tamp_compressor_compress_and_flush(TampCompressor* compressor, unsigned char* output, size_t output_size,

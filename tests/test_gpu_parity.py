@@ -363,8 +363,11 @@ def test_reference_named_c_api(ta, oracle):
         r = lib.tamp_compressor_compress_and_flush(c, out, 4096, C.byref(written), src, len(data), C.byref(consumed), False)
         st, want = oracle.compress(data, window=conf.window, literal=8, extended=bool(conf.extended), dictionary=dic)
         assert (r, bytes(out[: written.value]), consumed.value) == (st, want, len(data))
-        # a second call on the same object would need carried state: refused, not emulated
-        assert lib.tamp_compressor_compress_and_flush(c, out, 4096, C.byref(written), src, 10, C.byref(consumed), False) == -1
+        # a second call on the same object is the next segment of the same stream (window carried in `window`)
+        r = lib.tamp_compressor_compress_and_flush(c, out, 4096, C.byref(written), src, 10, C.byref(consumed), False)
+        st2, both = oracle.stream_script([("write", data), ("flush", False), ("write", data[:10]), ("flush", False)],
+                                         window=conf.window, literal=8, extended=bool(conf.extended), dictionary=dic)
+        assert (r, st2, bytes(out[: written.value]), consumed.value) == (0, 0, both[len(want):], 10)
         # decode: conf from the header ...
         if dic is not None:
             C.memmove(window, dic, W)
@@ -387,3 +390,92 @@ def test_reference_named_c_api(ta, oracle):
     want = oracle.compress(b"abcabcabc")[1]
     cbuf = (C.c_ubyte * len(want)).from_buffer_copy(want)
     assert lib.tamp_decompressor_decompress(d, (C.c_ubyte * 64)(), 64, None, cbuf, len(want), None) == -3
+
+
+def test_reference_named_streaming_c_api(ta, oracle):
+    """tamp_compressor_flush / _reset_dictionary / tamp_compress_stream / tamp_decompress_stream under the reference's
+    names (compressor.h:193,217,338; decompressor.h:190), with the library's own memory adaptors (common.h:255-290)."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    class MemReader(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class MemWriter(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("capacity", C.c_size_t), ("pos", C.c_size_t)]
+
+    sz = C.POINTER(C.c_size_t)
+    for fn, args in (("tamp_compressor_init", [C.c_void_p, C.c_void_p, C.c_void_p]),
+                     ("tamp_compressor_compress_and_flush", [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_void_p,
+                                                             C.c_size_t, sz, C.c_bool]),
+                     ("tamp_compressor_flush", [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_bool]),
+                     ("tamp_compressor_reset_dictionary", [C.c_void_p, C.c_void_p, C.c_size_t, sz]),
+                     ("tamp_compress_stream", [C.c_void_p] * 5 + [sz, sz, C.c_void_p, C.c_void_p]),
+                     ("tamp_decompress_stream", [C.c_void_p] * 5 + [sz, sz, C.c_void_p, C.c_void_p]),
+                     ("tamp_decompressor_init", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8])):
+        getattr(lib, fn).restype = C.c_int8
+        getattr(lib, fn).argtypes = args
+    mem_read = C.cast(lib.tamp_stream_mem_read, C.c_void_p)
+    mem_write = C.cast(lib.tamp_stream_mem_write, C.c_void_p)
+    text = wl.synth_text(1, 9000, first_index=31)[0].tobytes()
+    d1, d2 = text[:2500], text[2500:9000]
+
+    # 1. flush tokens + reset_dictionary, the ctests/test_compressor.c:403-613 shape
+    for lazy in (0, 1):
+        conf = TampConf(window=10, literal=8, extended=1, dictionary_reset=1, lazy_matching=lazy)
+        window, comp = (C.c_ubyte * 1024)(), (C.c_ubyte * 48)()
+        assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+        got = bytearray()
+        out, w, k = (C.c_ubyte * 16384)(), C.c_size_t(0), C.c_size_t(0)
+        s1 = (C.c_ubyte * len(d1)).from_buffer_copy(d1)
+        s2 = (C.c_ubyte * len(d2)).from_buffer_copy(d2)
+        assert lib.tamp_compressor_compress_and_flush(comp, out, 16384, C.byref(w), s1, len(d1), C.byref(k), True) == 0
+        got += bytes(out[: w.value])
+        assert lib.tamp_compressor_flush(comp, out, 16384, C.byref(w), True) == 0  # redundant: suppressed
+        assert w.value == 0
+        assert lib.tamp_compressor_reset_dictionary(comp, out, 16384, C.byref(w)) == 0
+        got += bytes(out[: w.value])
+        assert lib.tamp_compressor_compress_and_flush(comp, out, 16384, C.byref(w), s2, len(d2), C.byref(k), False) == 0
+        got += bytes(out[: w.value])
+        st, want = oracle.stream_script([("write", d1), ("flush", True), ("flush", True), ("reset",), ("write", d2),
+                                         ("flush", False)], dictionary_reset=True, lazy_matching=bool(lazy))
+        assert st == 0 and bytes(got) == want
+        assert bytes(ta.decompress(bytes(got))) == d1 + d2
+    conf = TampConf(window=10, literal=8, extended=1)
+    comp = (C.c_ubyte * 48)()
+    assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+    assert lib.tamp_compressor_reset_dictionary(comp, out, 16384, C.byref(w)) == -3  # compressor.c:846
+
+    # 2. callback stream API, ctests/test_stream.c round-trip shape
+    for ext in (1, 0):
+        conf = TampConf(window=10, literal=8, extended=ext)
+        assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+        src = (C.c_ubyte * len(text)).from_buffer_copy(text)
+        dst = (C.c_ubyte * 16384)()
+        rd, wr = MemReader(C.addressof(src), len(text), 0), MemWriter(C.addressof(dst), 16384, 0)
+        cin, cout = C.c_size_t(0), C.c_size_t(0)
+        assert lib.tamp_compress_stream(comp, mem_read, C.byref(rd), mem_write, C.byref(wr), C.byref(cin),
+                                        C.byref(cout), None, None) == 0
+        st, want = oracle.compress(text, extended=bool(ext))
+        assert (cin.value, cout.value, bytes(dst[: wr.pos])) == (len(text), len(want), want)
+        dec = (C.c_ubyte * 24)()
+        assert lib.tamp_decompressor_init(dec, None, window, 10) == 0
+        back = (C.c_ubyte * 16384)()
+        rd, wr = MemReader(C.addressof(dst), len(want), 0), MemWriter(C.addressof(back), 16384, 0)
+        assert lib.tamp_decompress_stream(dec, mem_read, C.byref(rd), mem_write, C.byref(wr), C.byref(cin),
+                                          C.byref(cout), None, None) == 0
+        assert (cin.value, cout.value, bytes(back[: wr.pos])) == (len(want), len(text), text)
+        # a writer that is too small: TAMP_WRITE_ERROR (common.h:163)
+        assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+        rd, wr = MemReader(C.addressof(src), len(text), 0), MemWriter(C.addressof(dst), 100, 0)
+        assert lib.tamp_compress_stream(comp, mem_read, C.byref(rd), mem_write, C.byref(wr), None, None, None,
+                                        None) == -12
