@@ -322,7 +322,7 @@ int tamp_amd_prof_read(unsigned long long* out6) {
         return 0;
     }
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(out6, g_prof, 96, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out6, g_prof, 128, hipMemcpyDeviceToHost);
     (void)hipMemset(g_prof, 0, 128);
     return 0;
 }

@@ -126,22 +126,21 @@ __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix)
            ((bytes4 >> 24) << (24 + kRemBits));
 }
 
-// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  Two stages of one LDS
-// round trip each: bytes 0..7 (where almost every candidate already differs), then 8..15.
+// Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  Branch-free: 64 lanes in
+// lockstep would walk every branch of a staged compare anyway, so all 16 bytes are fetched (five aligned dwords,
+// funnel-shifted by the byte phase) and the first differing byte is found with two 64-bit count-trailing-zeros.
 __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
     const uint32_t sh = c & 3u;
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
     const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ P[0];
     const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ P[1];
-    if (x0 | x1) return x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
-    const uint32_t w3 = w[3], w4 = w[4];
     const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ P[2];
     const uint32_t x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ P[3];
-    uint32_t res = 16;
-    if (x3) res = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
-    if (x2) res = 8 + ((uint32_t)__builtin_ctz(x2) >> 3);
-    return res;
+    const uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+    const uint32_t nlo = (uint32_t)__builtin_ctzll(lo | (1ull << 63)) >> 3;          // 0..7 (7 also when lo == 0)
+    const uint32_t nhi = 8u + ((uint32_t)__builtin_ctzll(hi | (1ull << 63)) >> 3);   // 8..15
+    return lo ? nlo : (hi ? nhi : 16u);
 }
 
 // Candidate whose bytes run past the newest window byte: the ring continues with the OLDEST window byte, i.e.
@@ -455,6 +454,7 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
         unsigned long long _n = __builtin_readcyclecounter(); \
         pt[i] += _n - pc;                                     \
         pc = _n;                                              \
+        if (a.dbg & (8u << (i))) return; /* truncation experiments: instruction counts up to this mark */ \
     } while (0)
 #else
 #define TAMP_PROF_MARK(i) \
@@ -716,6 +716,35 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         uint32_t sl = qstart[q], wrapmask = 0;
                         uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
                         TAMP_FINE(f0);
+                        if constexpr (!LAZY) {
+                            while (sl < s_hi) {
+#ifdef TAMP_PROF
+                                niter++;
+#endif
+                                const uint32_t e = e_next;
+                                sl++;
+                                e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // one past the range at the end: harmless
+                                // position-only entries: everything is "deep", the byte compare decides
+                                const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
+                                const uint32_t c = e & 0xFFFFu;
+                                const uint32_t d = c - q;              // distance from the oldest window byte
+                                const uint32_t i = (e + e_wp) & mask;  // window index (payload bits masked off)
+                                // in the window and the same bigram.  (Index W-1 cannot start a match: its limit
+                                // W - i = 1 rejects it below.)
+                                if (d <= W - 2 && (x & ((1u << kRemBits) - 1)) == 0) {
+                                    const uint32_t t = W - d;  // bytes before the candidate reaches the newest byte
+                                    if (t < 16) {
+                                        wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
+                                    } else {
+                                        uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
+                                        if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                                        const uint32_t l2 = min(len, min(cap_len, W - i));  // may not run past index W-1
+                                        const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                                        if (l2 >= 2 && k > key) key = k;
+                                    }
+                                }
+                            }
+                        } else
                         while (sl < s_hi) {
 #ifdef TAMP_PROF
                             niter++;
