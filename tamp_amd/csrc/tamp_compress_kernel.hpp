@@ -738,9 +738,11 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                                     } else {
                                         uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
                                         if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
-                                        const uint32_t l2 = min(len, min(cap_len, W - i));  // may not run past index W-1
-                                        const uint32_t k = (l2 << 16) | (0xFFFFu - i);
-                                        if (l2 >= 2 && k > key) key = k;
+                                        // key = length << 16 | (W - index): longest, then lowest index.  W - i is also
+                                        // the limit "may not run past index W-1"; a clipped length of 1 (index W-1)
+                                        // yields a key below every real match and is read as "no match" later.
+                                        const uint32_t lim_i = W - i;
+                                        key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
                                     }
                                 }
                             }
@@ -770,7 +772,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                                 } else {
                                     const uint32_t la = t == 16 && (x >> kRemBits) == 0 ? prefix_len16(ebuf, c, P) : len;
                                     const uint32_t l2 = min(la, lim);
-                                    const uint32_t k = (l2 << 16) | (0xFFFFu - i);
+                                    const uint32_t k = (l2 << 16) | (W - i);
                                     if (l2 >= 2 && k > key) key = k;
                                 }
                             }
@@ -787,7 +789,8 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         // Candidates in the last 15 window positions run past the newest byte, where the ring continues
                         // with the OLDEST byte; t = 1 (the newest byte itself) pairs with the oldest one and is therefore
                         // not in the index at all: test its first byte here.
-                        if (ebuf[q + W - 1] == (P[0] & 0xFFu)) wrapmask |= 2u;
+                        // (a match there needs the oldest byte to equal the pattern's second byte as well)
+                        if (ebuf[q + W - 1] == (P[0] & 0xFFu) && ebuf[q] == ((P[0] >> 8) & 0xFFu)) wrapmask |= 2u;
                         while (wrapmask) {
                             const uint32_t t = (uint32_t)__builtin_ctz(wrapmask);
                             wrapmask &= wrapmask - 1;
@@ -795,7 +798,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                             const uint32_t i = (e_wp + c) & mask;
                             if (i == mask) continue;
                             const uint32_t len = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_len, W - i));
-                            const uint32_t k = (len << 16) | (0xFFFFu - i);
+                            const uint32_t k = (len << 16) | (W - i);
                             if (len >= 2 && k > key) key = k;
                         }
                     }
@@ -832,7 +835,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         slow = (prev == b0 && (b1 == b0 || R == 1)) || len > minp + 11;
                     }
                     blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
-                    bidx[q] = (uint16_t)(0xFFFFu - (key & 0xFFFFu));
+                    bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
                     TAMP_FINE(f2);
                 }
                 __syncthreads();
@@ -883,9 +886,10 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         // positions), then let one lane per block list that block's token positions.
                         uint32_t pos = Walk::uni(wk.rd), total = 0, nseg = 0;
                         while (pos < nvalid && nseg < 64 && wk.ntok + total + 64 <= L.tokcap) {
-                            const uint32_t j = Walk::uni(jump16[pos]);
+                            const uint32_t jv = jump16[pos], cv = count8[pos];  // both reads in flight: one LDS round trip
+                            const uint32_t j = Walk::uni(jv);
                             if (j == pos) break;  // a position the state machine has to look at
-                            const uint32_t cpos = Walk::uni(count8[pos]);
+                            const uint32_t cpos = Walk::uni(cv);
                             if (lane == 0) {
                                 segpos[nseg] = (uint16_t)pos;
                                 segbase[nseg] = (uint16_t)total;
