@@ -37,6 +37,8 @@ enum {
 };
 typedef int8_t tamp_res;
 
+#define TAMP_AMD_WINDOW_BITS_EXACT 0x80 /* flag for tamp_batch_decompress's max_window_bits: no header pre-pass */
+
 /* Unpacked twin of TampConf (common.h:170-182).  One configuration per batch launch. */
 typedef struct TampAmdConf {
     uint8_t window;                /* 8..15 */
@@ -124,7 +126,11 @@ int tamp_batch_compress(const TampAmdConf *conf, const uint8_t *dictionary, cons
  *                                 (>= 1<<window bytes, prefix used; such a stream with dictionary == NULL gets
  *                                 TAMP_INVALID_CONF, where the Python surface raises ValueError,
  *                                 tamp/_c_decompressor.pyx:63-64)
- *   max_window_bits               streams whose header asks for more get TAMP_INVALID_CONF (decompressor.c:311)
+ *   max_window_bits               streams whose header asks for more get TAMP_INVALID_CONF (decompressor.c:311).  When it
+ *                                 is above 8 the call first reads the headers of the batch (one tiny kernel and a
+ *                                 4-byte copy, which waits for `stream`) to size the on-chip windows for the largest
+ *                                 one actually present; OR in TAMP_AMD_WINDOW_BITS_EXACT to skip that and stay fully
+ *                                 asynchronous (windows are then sized for max_window_bits itself)
  *   in_consumed                   optional (may be NULL): compressed bytes consumed per stream
  */
 int tamp_batch_decompress(const uint8_t *dictionary, size_t dictionary_len, uint8_t max_window_bits, const uint8_t *in,

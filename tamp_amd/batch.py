@@ -152,8 +152,12 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
 
 
 def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None, max_window_bits: int = 15,
-                     device: int = 0, stream=None, timing: bool = False) -> BatchResult:
+                     scan_headers: bool = True, device: int = 0, stream=None, timing: bool = False) -> BatchResult:
     """Decompress many independent ``.tamp`` streams in one launch (configuration read from each header).
+
+    ``max_window_bits`` is the reference's limit (larger headers -> TAMP_INVALID_CONF).  With ``scan_headers`` the
+    library first looks at the batch's headers to size its on-chip windows for the largest one present (one tiny
+    kernel + a 4-byte copy that waits for the stream); pass ``scan_headers=False`` to stay fully asynchronous.
 
     ``out_cap`` (int or per-stream array) bounds each stream's output.  ``status[i]`` is the reference's code:
     2 (INPUT_EXHAUSTED) on normal completion, 1 (OUTPUT_FULL) if ``out_cap[i]`` was reached with work left,
@@ -161,6 +165,8 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
     """
     lib = _lib.load()
     lib.tamp_amd_set_timing(1 if timing else 0)
+    if not scan_headers:
+        max_window_bits |= _lib.WINDOW_BITS_EXACT
     if _is_torch(data):
         import torch
 

@@ -34,6 +34,7 @@ struct DeviceCtx {
     uint8_t* seed_dicts = nullptr;  // 3 x 32 KiB: literal<=5, ==6, >=7
     uint8_t* scratch = nullptr;     // decoder window slots
     size_t scratch_bytes = 0;
+    uint32_t* hdr_scan = nullptr;   // header pre-pass result (largest window in the batch)
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -200,6 +201,21 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     return TAMP_OK;
 }
 
+// Largest window (bits) any stream header of the batch asks for, among those the caller's limit admits.  LDS rows of the
+// decoders are sized from it instead of from the limit: a caller that passes the API default (15) for 1 KiB-window
+// streams would otherwise run at a fraction of the occupancy.
+__global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                        uint32_t limit, uint32_t* result) {
+    uint32_t m = 0;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        if (in_len[s] == 0) continue;
+        const uint32_t w = 8u + (in[in_off[s]] >> 5);  // header byte, decompressor.c:276-297
+        if (w <= limit && w > m) m = w;
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(result, m);
+}
+
 int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
                       const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                       const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
@@ -213,6 +229,24 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.seed_dicts = ctx->seed_dicts;
     a.scratch = nullptr;
     a.n_streams = (uint32_t)n_streams;
+    const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
+    max_wbits &= 0x7F;
+    if (!exact && max_wbits > 8 && max_wbits <= 15 && n_streams >= 256) {
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            if (!ctx->hdr_scan) HIP_OK(hipMalloc(&ctx->hdr_scan, 4));
+        }
+        uint32_t found = 0;
+        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 4, st));
+        const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
+        hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, (uint32_t)n_streams,
+                           (uint32_t)max_wbits, ctx->hdr_scan);
+        HIP_OK(hipMemcpyAsync(&found, ctx->hdr_scan, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        // streams above the limit fail with TAMP_INVALID_CONF under either value; nothing valid exceeds `found`
+        if (found >= 8 && found < max_wbits) max_wbits = (uint8_t)found;
+        if (found == 0) max_wbits = 8;
+    }
     a.max_wbits = max_wbits;
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
