@@ -137,12 +137,18 @@ struct SegmentSpec {  // streaming Compressor over the engine: how this piece of
     uint8_t flags;  // kSegResume | kSegSave | kSegFlushToken
 };
 
-uint32_t pick_block(uint32_t W, uint32_t max_in_len) {
-    // positions matched per epoch: the whole stream when it is short, else 2048 (LDS ~30 KB at W=1024,
-    // five workgroups per CU); always a multiple of 64 (the walk chases 64 positions per register)
+uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy) {
+    // positions matched per epoch: the whole stream when it is short, else 2048 -- or 1536 when the smaller LDS
+    // footprint lets one more workgroup live on a CU (W = 1024: 25 KB instead of 30 KB, six instead of five; the extra
+    // occupancy outweighs the third epoch of a 4 KiB stream).  Always a multiple of 64 (the walk chases 64 positions
+    // per register).
     uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
-    if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = blk < v ? blk : align_up(v, 64); }
     if (blk > 2048) blk = 2048;
+    if (blk > 1536) {
+        const uint32_t lds_cu = 160u * 1024u;
+        if (lds_cu / CompressLds(W, 1536, packed, lazy).total > lds_cu / CompressLds(W, blk, packed, lazy).total) blk = 1536;
+    }
+    if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
     return blk;
@@ -181,8 +187,8 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.prof = g_prof;
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     const uint32_t W = 1u << conf->window;
-    a.blk = pick_block(W, max_in_len);
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
+    a.blk = pick_block(W, max_in_len, packed, a.lazy != 0);
     const CompressLds L(W, a.blk, packed, a.lazy != 0);
     if (L.total > ctx->lds_per_block) {
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
