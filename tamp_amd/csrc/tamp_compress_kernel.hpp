@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         // again soon); a block that ends cleanly doubles it back up to the LDS capacity.
         uint32_t cur_blk = a.blk;
 #ifdef TAMP_PROF
-        unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long pc = __builtin_readcyclecounter();
 #endif
         for (;;) {
@@ -570,6 +570,9 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a.blk + 128; k += nt) blen[k] = 0x80;  // sentinels
                 __syncthreads();
                 TAMP_PROF_MARK(0);
+#ifdef TAMP_PROF
+                pt[12] += 1, pt[13] += nvalid;  // epochs, positions matched
+#endif
 
                 // ---------------- index: counting sort of buffer positions by bigram ----------------
                 const uint32_t NE = nvalid ? W + nvalid : 0;  // positions 0..NE-1 (every query's own bigram included)
@@ -1152,7 +1155,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         }
 #ifdef TAMP_PROF
         if (tid == 0 && a.prof)
-            for (int i = 0; i < 12; i++) atomicAdd(&a.prof[i], pt[i]);
+            for (int i = 0; i < 16; i++) atomicAdd(&a.prof[i], pt[i]);
 #endif
         __syncthreads();  // ctl / LDS reuse by the next stream
     }

@@ -1,0 +1,27 @@
+"""Decoder timing, both variants (TAMP_AMD_DECODER=wave|lane), default max_window_bits.  Dev tool."""
+import sys, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import numpy as np, torch
+from tamp_amd import _lib
+if os.environ.get('TAMP_VAR'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libtamp_var%s.so' % os.environ['TAMP_VAR'])
+import tamp_amd
+from tamp_amd import workloads as wl
+dev = torch.device('cuda:0')
+def run(name, rows, **kw):
+    n, L = rows.shape
+    off, ln = wl.csr_for_fixed(n, L)
+    data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
+    r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=L, **kw)
+    cap = torch.full((n,), L, dtype=torch.int32, device=dev)
+    for mode in ('wave', 'lane'):
+        os.environ['TAMP_AMD_DECODER'] = mode
+        ms = []
+        for it in range(4):
+            d = tamp_amd.decompress_batch(r.out, r.out_off, r.out_len, out_cap=cap, dictionary=kw.get('dictionary'), timing=True)
+            ms.append(d.kernel_ms)
+        ok = bool((d.out[:n*L].cpu().numpy() == rows.reshape(-1)).all())
+        print(f"{name:26s} {mode}: {min(ms):7.3f} ms  {n*L/min(ms)/1e6:7.1f} GB/s out  ok={ok}", flush=True)
+run("text 65536x4K w10 ext", wl.synth_text(65536, 4096))
+run("text 65536x4K w10 v1", wl.synth_text(65536, 4096), extended=False)
+run("telemetry 1Mx256 w8 l7", wl.telemetry(1<<20, 256), window=8, literal=7)
