@@ -479,3 +479,32 @@ def test_reference_named_streaming_c_api(ta, oracle):
         rd, wr = MemReader(C.addressof(src), len(text), 0), MemWriter(C.addressof(dst), 100, 0)
         assert lib.tamp_compress_stream(comp, mem_read, C.byref(rd), mem_write, C.byref(wr), None, None, None,
                                         None) == -12
+
+
+def test_mixed_window_batch_and_header_prepass(ta, oracle):
+    """BASELINE config 4 shape: one decode launch over streams whose windows differ (w in 8..12).  The window limit
+    keeps the reference's meaning (decompressor.c:311) whether the library sizes its on-chip windows from a header
+    pre-pass (default) or from the limit itself (scan_headers=False)."""
+    from tamp_amd import workloads as wl
+
+    rng = random.Random(4)
+    rows = wl.synth_text(640, 1500, first_index=900)
+    streams, plain, wbits = [], [], []
+    for i in range(rows.shape[0]):
+        w = rng.choice([8, 9, 10, 11, 12])
+        data = rows[i].tobytes()[: rng.randrange(1, 1500)]
+        st, comp = oracle.compress(data, window=w, extended=bool(i & 1))
+        assert st == 0
+        streams.append(comp), plain.append(data), wbits.append(w)
+    for limit in (15, 12, 10, 8):
+        for scan in (True, False):
+            res = ta.decompress_batch(streams, out_cap=1500, max_window_bits=limit, scan_headers=scan)
+            for i, (p, w) in enumerate(zip(plain, wbits)):
+                if w > limit:
+                    assert int(res.status[i]) == -3, (limit, scan, i)
+                else:
+                    assert int(res.status[i]) == 2 and res.stream(i) == p, (limit, scan, i, w)
+    # every header above the limit: nothing decodes, nothing crashes
+    big = [s for s, w in zip(streams, wbits) if w == 12] * 3
+    res = ta.decompress_batch(big[:300], out_cap=1500, max_window_bits=9)
+    assert (np.asarray(res.status[:300]) == -3).all()
