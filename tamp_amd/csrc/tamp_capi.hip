@@ -212,14 +212,20 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
 // streams would otherwise run at a fraction of the occupancy.
 __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                         uint32_t limit, uint32_t* result) {
-    uint32_t m = 0;
+    uint32_t m = 0, longest = 0;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        if (in_len[s] == 0) continue;
+        const uint32_t len = in_len[s];
+        if (len == 0) continue;
+        longest = len > longest ? len : longest;
         const uint32_t w = 8u + (in[in_off[s]] >> 5);  // header byte, decompressor.c:276-297
         if (w <= limit && w > m) m = w;
     }
     m = wave_max_u32(m);
-    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(result, m);
+    longest = wave_max_u32(longest);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (m) atomicMax(result, m);
+        atomicMax(result + 1, longest);
+    }
 }
 
 int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
@@ -236,31 +242,45 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.scratch = nullptr;
     a.n_streams = (uint32_t)n_streams;
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
+    uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)
     max_wbits &= 0x7F;
     if (!exact && max_wbits > 8 && max_wbits <= 15 && n_streams >= 256) {
         {
             std::lock_guard<std::mutex> lock(g_mu);
-            if (!ctx->hdr_scan) HIP_OK(hipMalloc(&ctx->hdr_scan, 4));
+            if (!ctx->hdr_scan) HIP_OK(hipMalloc(&ctx->hdr_scan, 8));
         }
-        uint32_t found = 0;
-        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 4, st));
+        uint32_t scan[2] = {0, 0};
+        uint32_t& found = scan[0];
+        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 8, st));
         const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
         hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, (uint32_t)n_streams,
                            (uint32_t)max_wbits, ctx->hdr_scan);
-        HIP_OK(hipMemcpyAsync(&found, ctx->hdr_scan, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(scan, ctx->hdr_scan, 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         // streams above the limit fail with TAMP_INVALID_CONF under either value; nothing valid exceeds `found`
         if (found >= 8 && found < max_wbits) max_wbits = (uint8_t)found;
         if (found == 0) max_wbits = 8;
+        longest_in = scan[1];
     }
     a.max_wbits = max_wbits;
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
     // Decoder choice: one wavefront per stream (scalar token loop, window in LDS, 64-lane copies) unless the batch is
     // a very large number of streams, where one lane per stream fills the chip and avoids per-stream set-up.
+    // Lane-per-stream works in rounds of `capacity` streams (LDS rows limit the resident lanes) and a round lasts as long
+    // as its longest stream; per byte it is about twice as fast as wave-per-stream, whose time follows the total bytes.
+    // So: lanes when the rounds are at least ~60 % full.
     const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" (tuning / tests)
-    const bool many = n_streams >= ((size_t)1 << 19);
-    const bool use_wave = force ? (force[0] == 'w') : !(many && max_wbits <= kLdsWinBits);
+    const bool bulk = longest_in >= 512;  // short messages: the lean lane build (no bulk path, smaller rows)
+    bool lanes_pay = false;
+    if (valid_bits && max_wbits <= kLdsWinBits) {
+        const uint32_t lds = bulk ? lane_decoder_lds(max_wbits) : kWave * ((1u << max_wbits) + 4);
+        const size_t per_cu = std::min<size_t>(160 * 1024 / lds, 16);
+        const size_t capacity = (size_t)ctx->cu_count * per_cu * kWave;
+        const size_t rounds = (n_streams + capacity - 1) / capacity;
+        lanes_pay = n_streams * 10 >= rounds * capacity * 6;
+    }
+    const bool use_wave = force ? (force[0] == 'w') : !lanes_pay;
     if (valid_bits && use_wave) {
         const uint32_t waves = max_wbits <= 12 ? 4 : 1;
         const uint32_t lds = decode_wave_lds(max_wbits, waves);
@@ -277,16 +297,17 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     }
     if (valid_bits && max_wbits <= kLdsWinBits) {
         // windows in LDS: one 64-lane workgroup per 64 streams, one padded row per lane
-        a.lds_row = (1u << max_wbits) + 4;
-        const uint32_t lds = kWave * a.lds_row;
+        a.lds_row = (1u << max_wbits) + (bulk ? kLaneRowPad : 4u);
+        const uint32_t lds = bulk ? lane_decoder_lds(max_wbits) : kWave * a.lds_row;
         const uint32_t per_cu = (uint32_t)(160 * 1024 / lds) < 16 ? (uint32_t)(160 * 1024 / lds) : 16;
         size_t groups = (n_streams + kWave - 1) / kWave;
         const size_t resident = (size_t)ctx->cu_count * per_cu;
         if (groups > resident * 4) groups = resident * 4;  // grid-stride beyond a few waves of workgroups
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        auto lane_kernel = bulk ? tamp_decompress_kernel<true, true> : tamp_decompress_kernel<true, false>;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(lane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
         timing_begin(st);
-        hipLaunchKernelGGL(tamp_decompress_kernel<true>, dim3((uint32_t)groups), dim3(kWave), lds, st, a);
+        hipLaunchKernelGGL(lane_kernel, dim3((uint32_t)groups), dim3(kWave), lds, st, a);
         timing_end(st);
         HIP_OK(hipGetLastError());
         return TAMP_OK;
@@ -316,7 +337,7 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     }
     a.scratch = ctx->scratch;
     timing_begin(st);
-    hipLaunchKernelGGL(tamp_decompress_kernel<false>, dim3(grid), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL((tamp_decompress_kernel<false, false>), dim3(grid), dim3(threads), 0, st, a);
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;

@@ -40,8 +40,37 @@ struct DecompressArgs {
     uint8_t max_wbits;
 };
 
-constexpr uint32_t kLdsWinBits = 10;  // largest window kept in LDS: 64 lanes x (2^10 + 4) B = 64.25 KiB per workgroup
-// padded row of (1 << max_wbits) + 4 bytes per lane: lane l, index i -> bank (l * (row/4) + i/4) % 64 = (l + i/4) % 64
+constexpr uint32_t kLdsWinBits = 10;  // largest window kept in LDS: 64 lanes x (2^10 + 36) B = 66 KiB per workgroup
+// LDS variant, per 64-lane workgroup: [128 B prefix-code LUT][64 x 36 B output staging][64 window rows].  A row is
+// (1 << max_wbits) + 36 bytes: 32 bytes of slack behind the window (16 that mirror its first bytes when a write runs
+// over the end, 16 so that 16-byte reads near the end stay inside the row) + 4 so that the row stride in dwords is odd
+// (lanes touching the same index hit different banks).
+constexpr uint32_t kLaneRowPad = 36, kLaneStagePad = 84;  // stage: 4 pieces of 16 B + 15 carried bytes, odd dword stride
+__host__ __device__ constexpr uint32_t lane_decoder_lds(uint32_t max_wbits) {
+    return 128u + kWave * kLaneStagePad + kWave * ((1u << max_wbits) + kLaneRowPad);
+}
+
+struct B16 {
+    uint32_t w[4];
+};
+// 16 bytes at any address (gfx950 runs with unaligned DS / global access enabled: one ds_read_b128 / global_load_dwordx4)
+__device__ __forceinline__ B16 ld16(const uint8_t* p) {
+    B16 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st16(uint8_t* p, const B16& v) { __builtin_memcpy(p, &v, 16); }
+// first `k` bytes (0..16) from `a`, the rest from `b`
+__device__ __forceinline__ B16 blend16(const B16& a, const B16& b, uint32_t k) {
+    B16 r;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t lo = 4u * (uint32_t)j;
+        const uint32_t m = k >= lo + 4 ? 0xFFFFFFFFu : (k <= lo ? 0u : (1u << (8 * (k - lo))) - 1u);
+        r.w[j] = (a.w[j] & m) | (b.w[j] & ~m);
+    }
+    return r;
+}
 
 // Prefix-code reader for the symbol that follows the 0 flag (decompressor.c:52-104).  `b` holds the
 // upcoming bits left-aligned; returns the symbol and its code length, or -1 when `avail` is too small.
@@ -69,12 +98,34 @@ __device__ __forceinline__ int read_symbol(uint32_t b, uint32_t avail, uint32_t&
     return sym;
 }
 
-template <bool LDSWIN>
+// LDSWIN: window rows in LDS (else per-lane slots of a global scratch slab).  BULK (LDS variant only): the straight-line
+// bulk path with its LUT / output stage / row slack is compiled in; batches of short messages take the lean build,
+// which fits more workgroups on a CU.
+template <bool LDSWIN, bool BULK = false>
 __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(DecompressArgs a) {
+    static_assert(LDSWIN || !BULK, "the bulk path needs the window in LDS");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    uint8_t* const win = LDSWIN ? smem + threadIdx.x * a.lds_row : a.scratch + ((size_t)gtid << a.max_wbits);
+    uint8_t* const lut = smem;                                         // LDS variant only
+    uint8_t* const stg = smem + 128 + threadIdx.x * kLaneStagePad;      // LDS variant only
+    uint8_t* const win = LDSWIN ? smem + (BULK ? 128 + kWave * kLaneStagePad : 0u) + threadIdx.x * a.lds_row
+                                : a.scratch + ((size_t)gtid << a.max_wbits);
+    if constexpr (BULK) {
+        // prefix-code LUT: index = the 7 bits after the leading 1 of a code word -> (extra bits << 4) | symbol
+        // (decompressor.c:52-57 restated from the code table, compressor.c:33-36)
+        for (uint32_t v = threadIdx.x; v < 128; v += blockDim.x) {
+            const uint64_t codes_lo = 0x2b2624140b080300ull, codes_hi = 0x00ab27aa9594544bull, nbits = 0x979998877765532ull;
+            uint32_t entry = 0;
+            for (int s = 1; s < 15; s++) {
+                const uint32_t l = (uint32_t)((nbits >> (4 * s)) & 15) - 1u;  // code length without the flag: 2..8
+                const uint32_t code = (uint32_t)((s < 8 ? codes_lo >> (8 * s) : codes_hi >> (8 * (s - 8))) & 0xFF);
+                if ((code & ((1u << (l - 1)) - 1)) == (v >> (7 - (l - 1)))) entry = ((l - 1) << 4) | (uint32_t)s;
+            }
+            lut[v] = (uint8_t)entry;
+        }
+        __syncthreads();
+    }
 
     for (uint32_t s = gtid; s < a.n_streams; s += nthreads) {
         const uint8_t* const in = a.in + a.in_off[s];
@@ -86,7 +137,7 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
 
         // output staging: bytes collect in `oacc` and leave as one aligned dword
         uint32_t oacc = 0, on = 0;
-        const bool out_aligned = (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+        bool out_aligned = (reinterpret_cast<uintptr_t>(out) & 3) == 0;
         auto emit = [&](uint32_t b) {
             if (out_aligned) {
                 oacc |= b << (8 * on);
@@ -162,7 +213,218 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                 }
             };
 
+            bool first_pass = true;
+            for (;;) {  // LDS variant: bulk path and exact loop alternate; otherwise a single pass of the exact loop
+            bool resume = false;
+            uint32_t budget = 0xFFFFFFFFu;  // tokens the exact loop may take before the bulk path is tried again
+            // short streams (telemetry messages) are over before the bulk path has paid for seeding its window row
+            const bool use_bulk = BULK && n >= hs + 160;
+            if constexpr (BULK) if (use_bulk) {
+                // ================= bulk path: one token (or one 16-byte piece of a long one) per lane and iteration =================
+                // Every lane keeps its own stream going in lock step with the other 63.  A step is straight-line code:
+                // decode from a 64-bit bit window (input arrives 16 bytes at a time, prefetched 16 bytes ahead), read the
+                // 16 source bytes with one unaligned LDS read, merge the first `wlen` of them into the window row with a
+                // read-modify-write, append them to a 32-byte output stage that leaves as 16-byte stores.  Anything the
+                // straight-line code does not cover -- the last ~48 input bytes, output about to fill up, FLUSH, an
+                // out-of-bounds or self-overlapping extended match -- ends the bulk path for that lane at a token
+                // boundary; the reference-exact loop below finishes the stream from the same bit position.
+                if (first_pass) {
+                    for (uint32_t k = 0; k < W; k += 16) st16(win + k, ld16(seed + k));  // window <- dictionary
+                } else {
+                    for (uint32_t k = filled; k < W; k++) win[k] = seed[k];  // after a dictionary reset in the exact loop
+                    emit_flush();
+                }
+                first_pass = false;
+                filled = W;
+                uint32_t T = 8 * ip - nb;  // bits consumed from the start of the stream
+                uint32_t sp = T >> 3, si = 0;  // input chunks [sp, sp+16) and [sp+16, sp+32); si: next dword of `ca`
+                bool fast = sp + 32 <= n && cap - op >= 16;
+                // Input pipeline: `ca` is being consumed, `cn` is the next 16 bytes (complete), `cb` is in flight.  Global
+                // loads and stores are issued only at the I/O points below (every 4th step, the same step for all 64
+                // lanes) and what they fetch is first touched at the next I/O point: stores share the vector-memory
+                // counter with loads on gfx9, so a wait inside the step code would sit out every store latency.
+                B16 ca = {{0, 0, 0, 0}}, cn = {{0, 0, 0, 0}}, cb = {{0, 0, 0, 0}};
+                bool cn_valid = false, cb_valid = false;
+                uint32_t ld_off = sp + 16;  // next chunk to fetch
+                uint64_t fb = 0;  // upcoming bits, left aligned
+                uint32_t fn = 0;  // valid bits in fb
+                if (fast) {
+                    cb = ld16(in + sp);
+                    ca = cb;
+                    cb = ld16(in + sp + 16);
+                    cn = cb;
+                    cn_valid = true;
+                    ld_off = sp + 32;
+                    fb = (uint64_t)__builtin_bswap32(ca.w[0]) << (32 + (T & 7));  // first dword, bits before T dropped
+                    fn = 32 - (T & 7);
+                    si = 1;
+                    budget = 2;
+                }
+                const uint32_t T_in = T;
+                uint32_t T_mark = T;  // bit position at the reference's most recent refill (it decides the consumed count)
+                uint32_t on16 = 0, obase = op;  // bytes in the output stage; bytes already stored
+                uint32_t pend = 0, p_w = 0, p_off = 0, p_kind = 0, p_byte = 0;  // rest of a token longer than 16 bytes
+                auto refill32 = [&]() -> bool {
+                    if (si == 4) {
+                        if (!cn_valid) return false;  // the pipeline ran dry (a streak of long tokens, or the end of the input)
+                        ca = cn;
+                        cn_valid = false;
+                        sp += 16;
+                        si = 0;
+                    }
+                    const uint32_t w = si == 0 ? ca.w[0] : (si == 1 ? ca.w[1] : (si == 2 ? ca.w[2] : ca.w[3]));
+                    fb |= (uint64_t)__builtin_bswap32(w) << (32 - fn);
+                    fn += 32;
+                    si++;
+                    return true;
+                };
+                auto flush_blocks = [&]() {  // whole 16-byte blocks of the stage -> HBM, the rest moves to the front
+                    const uint32_t nblk = on16 >> 4;
+                    for (uint32_t b = 0; __ballot(b < nblk); b++)
+                        if (b < nblk) st16(out + obase + 16 * b, ld16(stg + 16 * b));
+                    if (nblk) {
+                        st16(stg, ld16(stg + 16 * nblk));
+                        obase += 16 * nblk;
+                        on16 &= 15;
+                    }
+                };
+                uint32_t step = 0;
+                enum { kLit = 0, kCopy = 1, kFill = 2 };
+                while (__ballot(fast)) {
+                    if ((step++ & 3) == 0) {  // ---- I/O point ----
+                        flush_blocks();
+                        if (fast) {
+                            if (cb_valid && !cn_valid) {
+                                cn = cb;
+                                cn_valid = true;
+                                cb_valid = false;
+                            }
+                            if (!cb_valid && ld_off + 16 <= n) {
+                                cb = ld16(in + ld_off);
+                                ld_off += 16;
+                                cb_valid = true;
+                            }
+                        }
+                    }
+                    if (!fast) continue;
+                    if (pend == 0) {  // ---- next token: peek, then commit or leave ----
+                        const uint32_t T0 = T;
+                        bool ok = fn >= 32 || refill32();
+                        uint32_t used = 0, tok = 0, wl = 0;
+                        uint32_t mark = T0;  // the reference refills at the top of every token (decompressor.c:357-365,431-445)
+                        if (ok) {
+                            if (fb >> 63) {  // literal, decompressor.c:466-482
+                                p_byte = (uint32_t)((fb << 1) >> (64 - lbits));
+                                used = 1 + lbits, tok = 1, wl = 1, p_kind = kLit;
+                                ok = op < cap;
+                            } else {
+                                uint32_t sym = 0;
+                                used = 2;
+                                if ((fb >> 62) & 1) {
+                                    const uint32_t e = lut[(uint32_t)(fb >> 55) & 0x7F];
+                                    sym = e & 15, used = 2 + (e >> 4);
+                                }
+                                if (sym == kSymFlush) {
+                                    ok = false;
+                                } else if (!extended || sym < kSymRle) {  // plain match, decompressor.c:529-572
+                                    tok = sym + minp;
+                                    p_off = (uint32_t)((fb << used) >> (64 - wbits));
+                                    used += wbits;
+                                    wl = tok, p_kind = kCopy;
+                                    ok = p_off + tok <= W && tok <= cap - op;
+                                } else {  // RLE / extended match, decompressor.c:114-273
+                                    fb <<= used, fn -= used, T += used;
+                                    ok = fn >= 32 || refill32();
+                                    if (ok) {
+                                        const uint32_t trailing = sym == kSymRle ? 4u : 3u;
+                                        uint32_t h = 0, u = 1;
+                                        if (fb >> 63) {
+                                            const uint32_t e = lut[(uint32_t)(fb >> 56) & 0x7F];
+                                            h = e & 15, u = 1 + (e >> 4);
+                                        }
+                                        const uint32_t value = (h << trailing) + (uint32_t)((fb << u) >> (64 - trailing));
+                                        u += trailing;
+                                        if (sym == kSymRle) {
+                                            tok = value + 2;
+                                            wl = min(min(tok, kRleWindowMax), W - wp);
+                                            p_kind = kFill, p_byte = win[(wp - 1) & mask];
+                                            ok = tok <= cap - op;
+                                        } else {
+                                            tok = value + minp + 12;
+                                            p_off = (uint32_t)((fb << u) >> (64 - wbits));
+                                            // ... and once more in front of the offset if its buffer (25..32 bits after the
+                                            // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
+                                            const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
+                                            if (nb_top - (T - T0) - u < wbits) mark = T + u;
+                                            u += wbits;
+                                            wl = min(tok, W - wp);
+                                            p_kind = kCopy;
+                                            // pieces are copied 16 bytes at a time: exact only if the window bytes written by an
+                                            // earlier piece are not a later piece's source
+                                            const bool overlap = p_off < wp + wl && wp < p_off + tok;
+                                            ok = p_off + tok <= W && tok <= cap - op && !overlap;
+                                        }
+                                        used = u;
+                                    }
+                                }
+                            }
+                        }
+                        if (!ok) {
+                            T = T0;
+                            fast = false;
+                            continue;
+                        }
+                        fb <<= used, fn -= used, T += used;
+                        pend = tok, p_w = wl;
+                        T_mark = mark;
+                    }
+                    // ---- one piece of at most 16 bytes ----
+                    const uint32_t olen = pend < 16 ? pend : 16u;
+                    const uint32_t wlen = p_w < olen ? p_w : olen;
+                    B16 src;
+                    if (p_kind == kCopy) {
+                        src = ld16(win + p_off);
+                    } else {
+                        const uint32_t r = p_kind == kFill ? p_byte * 0x01010101u : p_byte;
+                        src.w[0] = r, src.w[1] = r, src.w[2] = r, src.w[3] = r;
+                    }
+                    if (wlen) {  // window <- first wlen bytes (memmove semantics: the source was read first, common.c:58-86)
+                        st16(win + wp, blend16(src, ld16(win + wp), wlen));
+                        if (wp + wlen > W) {  // ran over the end: the overhang sits in the mirror, bring it to the front
+                            st16(win, blend16(ld16(win + W), ld16(win), wp + wlen - W));
+                        }
+                        wp = (wp + wlen) & mask;
+                    }
+                    st16(stg + on16, src);  // on16 <= 15 + 3 * 16 here: the stage is emptied at every I/O point
+                    on16 += olen, op += olen;
+                    pend -= olen, p_w -= wlen;
+                    if (p_kind == kCopy) p_off += olen;
+                }
+                // ---- hand over to the exact loop: staged output out, bit reader rebuilt from the bit position ----
+                flush_blocks();
+                for (uint32_t k = 0; k < on16; k++) out[obase + k] = stg[k];
+                if (T != T_in) {
+                    // the reference's buffer at this token boundary: everything its last refill pulled in
+                    last_flush = false;
+                    const uint32_t ip_ref = min(n, ((T_mark + 24) >> 3) + 1);
+                    bb = 0, nb = 0, stage = 0, ns = 0;
+                    for (uint32_t b = T >> 3; b < ip_ref; b++) {
+                        uint32_t byte = in[b], width = 8;
+                        if (b == (T >> 3)) byte &= 0xFFu >> (T & 7), width = 8 - (T & 7);
+                        bb |= byte << (32 - nb - width);
+                        nb += width;
+                    }
+                    ip = ip_ref;
+                }
+                // the dword staging of the exact loop assumes it starts on a dword of the output
+                out_aligned = ((reinterpret_cast<uintptr_t>(out) | op) & 3) == 0;
+            }
+
             for (;;) {  // decompressor.c:431-575
+                if (use_bulk && budget-- == 0) {  // back to the bulk path (it declines by itself near the end of the input)
+                    resume = true;
+                    break;
+                }
                 if (!(ip < n || nb)) break;
                 if (op == cap) { res = kOutputFull; break; }
                 refill();
@@ -290,6 +552,8 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                     }
                 }
             }
+            if (!resume) break;
+            }  // bulk / exact alternation
         } while (false);
 
         emit_flush();

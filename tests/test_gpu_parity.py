@@ -508,3 +508,41 @@ def test_mixed_window_batch_and_header_prepass(ta, oracle):
     big = [s for s, w in zip(streams, wbits) if w == 12] * 3
     res = ta.decompress_batch(big[:300], out_cap=1500, max_window_bits=9)
     assert (np.asarray(res.status[:300]) == -3).all()
+
+
+def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
+    """All three decoders (wave per stream; lane per stream lean / bulk build) on streams long enough for the bulk path:
+    plain, extended (RLE + extended-match tokens), custom dictionary, FLUSH / dictionary_reset streams, truncated
+    input and restricted output -- status, length, bytes and consumed counts against the oracle."""
+    from tamp_amd import workloads as wl
+
+    rng = random.Random(12)
+    text = [wl.synth_text(1, 6000, first_index=300 + i)[0].tobytes() for i in range(6)]
+    runs = [wl.lcg_runs(1, 5000, first_index=i)[0].tobytes() for i in range(3)]
+    stress = [wl.stress(3, 6000)[i].tobytes() for i in range(3)]
+    d10 = wl.synth_text(1, 1024, first_index=999)[0].tobytes()
+    cases = []  # (compressed, dictionary)
+    for data in text + runs + stress:
+        for kw in (dict(), dict(extended=False), dict(window=8), dict(window=9, literal=8, extended=True)):
+            st, comp = oracle.compress(data, **kw)
+            assert st == 0
+            cases.append((comp, None))
+    for data in text[:3]:
+        st, comp = oracle.compress(data, dictionary=d10)
+        cases.append((comp, d10))
+    for rec in load_golden("streaming.json"):  # FLUSH tokens, double-FLUSH resets
+        if rec["decodes"] and "dictionary" not in rec["conf"] and rec["conf"].get("window", 10) <= 10:
+            cases.append((unb64(rec["expected"]), None))
+    # truncated inputs
+    for comp, d in list(cases[:12]):
+        cases.append((comp[: rng.randrange(40, len(comp))], d))
+    for mode in ("wave", "lane"):
+        monkeypatch.setenv("TAMP_AMD_DECODER", mode)
+        for d in (None, d10):
+            group = [c for c, dd in cases if dd is d]
+            for cap in (8192, 1000, 4097, 3):
+                res = ta.decompress_batch(group, out_cap=cap, dictionary=d, max_window_bits=10)
+                for i, comp in enumerate(group):
+                    st, want, consumed = oracle.decompress(comp, dictionary=d, cap=cap, max_window_bits=10)
+                    assert (int(res.status[i]), res.stream(i)) == (st, want), (mode, cap, i, len(comp))
+                    assert int(res.in_consumed[i]) == consumed, (mode, cap, i)

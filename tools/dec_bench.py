@@ -22,6 +22,12 @@ def run(name, rows, **kw):
             ms.append(d.kernel_ms)
         ok = bool((d.out[:n*L].cpu().numpy() == rows.reshape(-1)).all())
         print(f"{name:26s} {mode}: {min(ms):7.3f} ms  {n*L/min(ms)/1e6:7.1f} GB/s out  ok={ok}", flush=True)
+for nn in (2048, 8192, 16384, 32768):
+    run(f"text {nn}x4K w10 ext", wl.synth_text(nn, 4096))
 run("text 65536x4K w10 ext", wl.synth_text(65536, 4096))
 run("text 65536x4K w10 v1", wl.synth_text(65536, 4096), extended=False)
 run("telemetry 1Mx256 w8 l7", wl.telemetry(1<<20, 256), window=8, literal=7)
+run("telemetry 64Kx256 w8 l7", wl.telemetry(1<<16, 256), window=8, literal=7)
+run("text 16384x16K w10", wl.synth_text(16384, 16384))
+run("text 65536x4K w8", wl.synth_text(65536, 4096), window=8)
+run("text 16384x4K w12", wl.synth_text(16384, 4096), window=12)
