@@ -278,7 +278,8 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         const size_t per_cu = std::min<size_t>(160 * 1024 / lds, 16);
         const size_t capacity = (size_t)ctx->cu_count * per_cu * kWave;
         const size_t rounds = (n_streams + capacity - 1) / capacity;
-        lanes_pay = n_streams * 10 >= rounds * capacity * 6;
+        // (short messages: a round is over so quickly that even a quarter-full one beats the wave decoder)
+        lanes_pay = n_streams * 10 >= rounds * capacity * (bulk ? 6 : 2);
     }
     const bool use_wave = force ? (force[0] == 'w') : !lanes_pay;
     if (valid_bits && use_wave) {

@@ -14,8 +14,9 @@ def run(name, rows, **kw):
     data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
     r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=L, **kw)
     cap = torch.full((n,), L, dtype=torch.int32, device=dev)
-    for mode in ('wave', 'lane'):
+    for mode in ('wave', 'lane', 'auto'):
         os.environ['TAMP_AMD_DECODER'] = mode
+        if mode == 'auto': del os.environ['TAMP_AMD_DECODER']
         ms = []
         for it in range(4):
             d = tamp_amd.decompress_batch(r.out, r.out_off, r.out_len, out_cap=cap, dictionary=kw.get('dictionary'), timing=True)
