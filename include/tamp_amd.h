@@ -64,6 +64,11 @@ void tamp_initialize_dictionary(unsigned char *buffer, size_t size, uint8_t lite
 /* Replaces tamp_compute_min_pattern_size (common.h:405, common.c:54-56). */
 int8_t tamp_compute_min_pattern_size(uint8_t window, uint8_t literal);
 
+/* Replaces tamp_window_copy (common.h:424, common.c:58-86): window[pos..pos+n) (wrapping with window_mask) <-
+ * window[offset..offset+n) with memmove semantics; *window_pos advances.  Caller validates offset + n. */
+void tamp_window_copy(unsigned char *window, uint16_t *window_pos, uint16_t window_offset, uint8_t match_size,
+                      uint16_t window_mask);
+
 /* Worst-case compressed size of an n-byte stream: header byte(s) + every byte a literal
  * (compressor.h flush table / SURVEY.md H7). */
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset);

@@ -21,6 +21,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SYMBOLS = (
     "tamp_initialize_dictionary",
     "tamp_compute_min_pattern_size",
+    "tamp_window_copy",
     "tamp_amd_compress_bound",
     "tamp_amd_device_count",
     "tamp_amd_version",

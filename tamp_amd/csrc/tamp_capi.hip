@@ -360,6 +360,21 @@ int8_t tamp_compute_min_pattern_size(uint8_t window, uint8_t literal) {
     return (int8_t)min_pattern_size(window, literal);
 }
 
+// common.h:424 / common.c:58-86: ring[pos..pos+n) (destination wraps) <- ring[off..off+n) (source does not), with the
+// result of reading every source byte before any is overwritten.  A host-side buffer utility of the reference's ABI
+// (the device decoders have their own copies of this rule); no codec work.
+void tamp_window_copy(unsigned char* window, uint16_t* window_pos, uint16_t window_offset, uint8_t match_size,
+                      uint16_t window_mask) {
+    unsigned char tmp[256];
+    for (unsigned i = 0; i < match_size; i++) tmp[i] = window[(size_t)window_offset + i];
+    uint16_t p = *window_pos;
+    for (unsigned i = 0; i < match_size; i++) {
+        window[p] = tmp[i];
+        p = (uint16_t)((p + 1) & window_mask);
+    }
+    *window_pos = p;
+}
+
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset) {
     return 1 + (dictionary_reset ? 1 : 0) + (n * ((size_t)literal + 1) + 7) / 8;
 }

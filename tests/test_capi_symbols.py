@@ -121,3 +121,33 @@ def test_c_caller_compiles_and_links(tmp_path):
     out = subprocess.check_output([str(exe)]).decode().split()
     assert out[:4] == ["2", "48", "24", "2"]
     assert out[4] == "002e2f2f"  # tests/test_pseudorandom.py:22-24: dictionary starts 00 '.' '/' '/'
+
+
+def test_window_copy_host_helper():
+    """tamp_window_copy (common.h:424): destination wraps, source does not, every source byte is read before any is
+    overwritten -- checked against a straight restatement for all distances around the overlap cases."""
+    import ctypes as C
+    import random
+
+    from tamp_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built")
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.tamp_window_copy.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_uint16, C.c_uint8, C.c_uint16]
+    lib.tamp_window_copy.restype = None
+    rng = random.Random(1)
+    W = 256
+    for _ in range(2000):
+        n = rng.randrange(0, 135)
+        off = rng.randrange(0, W - n + 1)
+        pos = (off + rng.randrange(-140, 141)) % W if rng.random() < 0.7 else rng.randrange(W)
+        start = bytes(rng.randrange(256) for _ in range(W))
+        buf = (C.c_ubyte * W).from_buffer_copy(start)
+        p = C.c_uint16(pos)
+        lib.tamp_window_copy(buf, C.byref(p), off, n, W - 1)
+        want = bytearray(start)
+        src = start[off : off + n]
+        for i, b in enumerate(src):
+            want[(pos + i) % W] = b
+        assert bytes(buf) == bytes(want) and p.value == (pos + n) % W, (off, pos, n)
