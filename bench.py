@@ -143,6 +143,25 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, rows, res, np)
+    if rank == 0 and world == 1:
+        # Not part of the metric: the same batch in the v1 format and the decode of what was just produced (round trip
+        # checked), kernel time by hipEvents, for the record next to the headline number.
+        try:
+            also = {}
+            ms = min(float(tamp_amd.compress_batch(data, off_t, len_t, timing=True, **dict(kw, extended=False)).kernel_ms)
+                     for _ in range(3))
+            also["compress_v1_format_MBps"] = round(in_bytes / (ms * 1e-3) / 1e6, 1)
+            back = None
+            ms = 1e30
+            for _ in range(3):
+                back = tamp_amd.decompress_batch(res.out, res.out_off, res.out_len, out_cap=slen, timing=True)
+                ms = min(ms, float(back.kernel_ms))
+            ok = bool((back.out_len == slen).all().item()) and bool(torch.equal(back.out[: n * slen], data[: n * slen]))
+            also["decompress_output_MBps"] = round(in_bytes / (ms * 1e-3) / 1e6, 1)
+            also["decompress_round_trip"] = "bit-exact" if ok else "MISMATCH"
+            result["also"] = also
+        except Exception as e:  # the extras must never cost the bench line
+            result["also"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed:
