@@ -832,10 +832,12 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     }
                     const uint32_t len = key >> 16;
                     // positions where poll_extended_handling does more than fall through (compressor.c:470-503)
-                    bool slow = lazy;  // lazy matching: every step goes through the state machine
-                    if (ext && !slow) {
+                    // (lazy matching: which match a step uses depends on the walk's state, so the length condition is
+                    // tested there and only the byte condition is recorded here)
+                    bool slow = false;
+                    if (ext) {
                         const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
-                        slow = (prev == b0 && (b1 == b0 || R == 1)) || len > minp + 11;
+                        slow = (prev == b0 && (b1 == b0 || R == 1)) || (!lazy && len > minp + 11);
                     }
                     blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
                     bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
@@ -851,6 +853,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
                 // the chain of plain steps starting there leaves the block (or the "slow" position it stops at) and how
                 // many tokens it emits on the way.
+                if constexpr (!LAZY)
                 for (uint32_t b = wave * 64; b < nvalid; b += (nt >> 6) * 64) {
                     const uint32_t sv = blen[b + lane];  // sentinels (0x80) beyond nvalid
                     const bool slowp = (sv & 0x80u) != 0;
@@ -884,7 +887,46 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         break;
                     }
                     const bool clean = wk.wr == wk.rd && wk.rle_count == 0 && wk.ext_count == 0;
-                    if (clean && wk.rd < nvalid) {
+                    if (LAZY && clean && !wk.lazy_valid && wk.rd + 1 < nvalid) {
+                        // Lazy matching, plain steps (compressor.c:576-619) as a scalar loop over the two match tables:
+                        // A = best match at p (blen/bidx), B = best match of the pattern at p+1 against the window as it
+                        // is at p (blen2/bidx2).  A step either emits its match / literal, or -- when B[p] beats it and
+                        // does not overlap the byte about to be written -- a literal, and the next step starts from B[p]
+                        // instead of A[p+1].  Tokens go to the list as position | state bits; the bits are made later.
+                        uint32_t p = Walk::uni(wk.rd);
+                        const uint32_t p_in = p;
+                        bool cached = false;
+                        uint32_t clen = 0, cidx = 0;
+                        while (p + 1 < nvalid && wk.ntok + 2 <= L.tokcap) {
+                            const uint32_t sv_l = blen[p], nl_l = blen2[p], ni_l = bidx2[p];  // one LDS round trip
+                            const uint32_t sv = Walk::uni(sv_l);
+                            if (sv & 0x80u) break;  // RLE territory: the state machine takes it
+                            const uint32_t len = cached ? clen : (sv & 0x1Fu);
+                            if (ext && len > minp + 11) break;  // extended match
+                            const uint32_t leftp = n - (w_p0 + p);
+                            const uint32_t R = leftp < kRing ? leftp : kRing;
+                            bool defer = false;
+                            uint32_t nlen = 0, nidx = 0;
+                            if (len >= minp && len <= 8 && R > len + 2) {
+                                nlen = Walk::uni(nl_l), nidx = Walk::uni(ni_l);
+                                const uint32_t wpos = (wk.wp_e + p) & mask;  // clean: everything consumed is written
+                                defer = nlen > len && (wpos < nidx || wpos >= nidx + nlen);  // validate_no_match_overlap, :185-188
+                            }
+                            if (lane == 0) toklist[wk.ntok] = (uint16_t)(p | (cached ? 0x1000u : 0u) | (defer ? 0x2000u : 0u));
+                            wk.ntok++;
+                            if (defer) {
+                                cached = true, clen = nlen, cidx = nidx;
+                                p += 1;
+                            } else {
+                                cached = false;
+                                p += len >= minp ? len : 1u;
+                            }
+                        }
+                        wk.rd = wk.wr = p;
+                        wk.lazy_valid = cached, wk.lazy_len = clen, wk.lazy_idx = cidx;
+                        if (p != p_in) continue;
+                    }
+                    if (!LAZY && clean && wk.rd < nvalid) {
                         // Plain steps: hop from block to block through the jump tables (one dependent LDS read per 64
                         // positions), then let one lane per block list that block's token positions.
                         uint32_t pos = Walk::uni(wk.rd), total = 0, nseg = 0;
@@ -1006,14 +1048,22 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     nb = stok[2 * (e & 0x7FFFu) + 1];
                     return true;
                 }
-                const uint32_t len = blen[e] & 0x1Fu;
+                uint32_t pos = e, len, idx;
+                if (LAZY) {  // position | 0x1000 (match cached by the previous step's probe) | 0x2000 (deferred: literal)
+                    pos = e & 0xFFFu;
+                    const bool cached = (e & 0x1000u) != 0;
+                    len = (e & 0x2000u) ? 0u : (cached ? (uint32_t)blen2[pos - 1] : (blen[pos] & 0x1Fu));
+                    idx = cached ? (uint32_t)bidx2[pos - 1] : (uint32_t)bidx[pos];
+                } else {
+                    len = blen[pos] & 0x1Fu, idx = bidx[pos];
+                }
                 if (len < minp) {  // compressor.c:625-632
-                    const uint32_t c = ebuf[W + e];
+                    const uint32_t c = ebuf[W + pos];
                     v = (1u << lbits) | c;
                     nb = lbits + 1;
                     return (c >> lbits) == 0;
                 }
-                v = (tok_code(len - minp) << wbits) | bidx[e];  // compressor.c:646-649
+                v = (tok_code(len - minp) << wbits) | idx;  // compressor.c:646-649
                 nb = tok_nbits(len - minp) + wbits;
                 return true;
             };
