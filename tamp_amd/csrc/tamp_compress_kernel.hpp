@@ -61,7 +61,7 @@ struct CompressArgs {
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
     uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, total;  // blen2/bidx2: lazy-matching probe results
-    uint32_t tokcap, obuf_words, jump, count;  // jump/count: byte offsets of the walk's tables inside `ent`
+    uint32_t tokcap, obuf_words, jump, count, vstep;  // jump/count/vstep: byte offsets of the walk's tables inside `ent`
     __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
         ebuf = o;
@@ -69,15 +69,18 @@ struct CompressLds {
         cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
         o += kHashBuckets * 2;
         tokcap = blk + kPendMax + kRing + 80;
+        // lazy matching walks (position, state) pairs: two table slots per position and the transitions themselves
+        const uint32_t vblk = lazy ? 2 * blk : blk;
         jump = align_up(tokcap * 2, 16);
-        count = jump + blk * 2;
+        count = jump + vblk * 2;
+        vstep = count + vblk;
         ent = o;  // (W + blk) index entries (u32 packed, or u16 position-only for the largest windows);
                   // the walk reuses the space for the token list (tokcap x u16)
         {
             // after the match phase the same space holds the token list (tokcap x u16) and the per-position
             // jump tables of the walk: jump target (u16) and token count (u8)
             const uint32_t index_bytes = (W + blk + 16) * (packed ? 4u : 2u);
-            const uint32_t walk_bytes = align_up(tokcap * 2, 16) + blk * 2 + blk + 16;
+            const uint32_t walk_bytes = align_up(tokcap * 2, 16) + vblk * 2 + vblk + 16 + (lazy ? vblk + 144 : 0);
             o += align_up(index_bytes > walk_bytes ? index_bytes : walk_bytes, 16);
         }
         blen = o;
@@ -482,6 +485,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
     uint16_t* const jump16 = reinterpret_cast<uint16_t*>(smem + L.ent + L.jump);   // alias, same reason
     uint8_t* const count8 = smem + L.ent + L.count;                                 // alias, same reason
+    uint8_t* const vstep = smem + L.ent + L.vstep;  // lazy builds: transition of every (position, state), same alias
     uint16_t* const segpos = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048);      // alias: walk scratch
     uint16_t* const segbase = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048 + 256);
     uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
@@ -550,6 +554,8 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         for (;;) {
             const uint32_t left = n - e_p0;
             const uint32_t nvalid = left < cur_blk ? left : cur_blk;
+            const uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
+            const uint8_t* const steps = LAZY ? vstep : blen;
             if (need_match) {
                 // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
                 const uint32_t room = cur_blk + kRing + kPendMax;
@@ -853,11 +859,38 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
                 // the chain of plain steps starting there leaves the block (or the "slow" position it stops at) and how
                 // many tokens it emits on the way.
-                if constexpr (!LAZY)
-                for (uint32_t b = wave * 64; b < nvalid; b += (nt >> 6) * 64) {
-                    const uint32_t sv = blen[b + lane];  // sentinels (0x80) beyond nvalid
+                // Lazy matching (compressor.c:576-619): a step starts either fresh (state 0: best match A[p] =
+                // blen/bidx) or from the match cached by the previous step's probe (state 1: B[p-1] = blen2/bidx2).  It
+                // emits its match / literal, or -- when the probe B[p] beats it and does not overlap the byte about to
+                // be written -- a literal, and hands B[p] to the next position.  That is a deterministic transition on
+                // the 2 x nvalid states v = 2p + state: it is tabulated here and chased with the same pointer doubling.
+                if constexpr (LAZY) {
+                    for (uint32_t v = tid; v < nv + 128 && v < 2 * a.blk + 128; v += nt) {
+                        uint32_t out = 0x80u;  // stop: the state machine takes this step
+                        const uint32_t pp = v >> 1, s1 = v & 1u;
+                        if (v < nv && pp + 1 < nvalid && !(s1 && pp == 0)) {
+                            const uint32_t sva = blen[pp];
+                            const uint32_t len = s1 ? (uint32_t)blen2[pp - 1] : (sva & 0x1Fu);
+                            if (!(sva & 0x80u) && !(ext && len > minp + 11)) {
+                                const uint32_t leftp = n - (e_p0 + pp);
+                                const uint32_t R = leftp < kRing ? leftp : kRing;
+                                bool defer = false;
+                                if (len >= minp && len <= 8 && R > len + 2) {
+                                    const uint32_t nlen = blen2[pp], nidx = bidx2[pp];
+                                    const uint32_t wpos = (e_wp + pp) & mask;  // clean chain: everything consumed is written
+                                    defer = nlen > len && (wpos < nidx || wpos >= nidx + nlen);  // validate_no_match_overlap, :185-188
+                                }
+                                out = defer ? 3u - s1 : 2u * (len >= minp ? len : 1u) - s1;  // v' - v
+                            }
+                        }
+                        vstep[v] = (uint8_t)out;
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t b = wave * 64; b < nv; b += (nt >> 6) * 64) {
+                    const uint32_t sv = steps[b + lane];  // sentinels (0x80) beyond the last state
                     const bool slowp = (sv & 0x80u) != 0;
-                    const uint32_t stepv = sv >= minp ? (sv & 0x1Fu) : 1u;
+                    const uint32_t stepv = LAZY ? (sv & 0x7Fu) : (sv >= minp ? (sv & 0x1Fu) : 1u);
                     // packed: target (relative, 0..79) | count << 8 | finished << 16
                     uint32_t st = slowp ? ((uint32_t)lane | (1u << 16)) : (((uint32_t)lane + stepv) | (1u << 8));
                     if ((st & 0xFFu) >= 64u) st |= 1u << 16;
@@ -867,7 +900,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tgt << 2), (int)st);
                         if (!(st >> 16)) st = (o2 & 0x100FFu) | (((st >> 8) & 0xFFu) + ((o2 >> 8) & 0xFFu)) << 8;
                     }
-                    if (b + lane < nvalid) {
+                    if (b + lane < nv) {
                         jump16[b + lane] = (uint16_t)(b + (st & 0xFFu));
                         count8[b + lane] = (uint8_t)((st >> 8) & 0xFFu);
                     }
@@ -887,50 +920,13 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                         break;
                     }
                     const bool clean = wk.wr == wk.rd && wk.rle_count == 0 && wk.ext_count == 0;
-                    if (LAZY && clean && !wk.lazy_valid && wk.rd + 1 < nvalid) {
-                        // Lazy matching, plain steps (compressor.c:576-619) as a scalar loop over the two match tables:
-                        // A = best match at p (blen/bidx), B = best match of the pattern at p+1 against the window as it
-                        // is at p (blen2/bidx2).  A step either emits its match / literal, or -- when B[p] beats it and
-                        // does not overlap the byte about to be written -- a literal, and the next step starts from B[p]
-                        // instead of A[p+1].  Tokens go to the list as position | state bits; the bits are made later.
-                        uint32_t p = Walk::uni(wk.rd);
-                        const uint32_t p_in = p;
-                        bool cached = false;
-                        uint32_t clen = 0, cidx = 0;
-                        while (p + 1 < nvalid && wk.ntok + 2 <= L.tokcap) {
-                            const uint32_t sv_l = blen[p], nl_l = blen2[p], ni_l = bidx2[p];  // one LDS round trip
-                            const uint32_t sv = Walk::uni(sv_l);
-                            if (sv & 0x80u) break;  // RLE territory: the state machine takes it
-                            const uint32_t len = cached ? clen : (sv & 0x1Fu);
-                            if (ext && len > minp + 11) break;  // extended match
-                            const uint32_t leftp = n - (w_p0 + p);
-                            const uint32_t R = leftp < kRing ? leftp : kRing;
-                            bool defer = false;
-                            uint32_t nlen = 0, nidx = 0;
-                            if (len >= minp && len <= 8 && R > len + 2) {
-                                nlen = Walk::uni(nl_l), nidx = Walk::uni(ni_l);
-                                const uint32_t wpos = (wk.wp_e + p) & mask;  // clean: everything consumed is written
-                                defer = nlen > len && (wpos < nidx || wpos >= nidx + nlen);  // validate_no_match_overlap, :185-188
-                            }
-                            if (lane == 0) toklist[wk.ntok] = (uint16_t)(p | (cached ? 0x1000u : 0u) | (defer ? 0x2000u : 0u));
-                            wk.ntok++;
-                            if (defer) {
-                                cached = true, clen = nlen, cidx = nidx;
-                                p += 1;
-                            } else {
-                                cached = false;
-                                p += len >= minp ? len : 1u;
-                            }
-                        }
-                        wk.rd = wk.wr = p;
-                        wk.lazy_valid = cached, wk.lazy_len = clen, wk.lazy_idx = cidx;
-                        if (p != p_in) continue;
-                    }
-                    if (!LAZY && clean && wk.rd < nvalid) {
+                    // (lazy: a match cached before this epoch began has no table entry -- the state machine takes that step)
+                    if (clean && wk.rd < nvalid && !(LAZY && wk.lazy_valid && wk.rd == e_pending)) {
                         // Plain steps: hop from block to block through the jump tables (one dependent LDS read per 64
-                        // positions), then let one lane per block list that block's token positions.
-                        uint32_t pos = Walk::uni(wk.rd), total = 0, nseg = 0;
-                        while (pos < nvalid && nseg < 64 && wk.ntok + total + 64 <= L.tokcap) {
+                        // positions / states), then let one lane per block list that block's tokens.
+                        uint32_t pos = LAZY ? 2 * Walk::uni(wk.rd) + (wk.lazy_valid ? 1u : 0u) : Walk::uni(wk.rd);
+                        uint32_t total = 0, nseg = 0;
+                        while (pos < nv && nseg < 64 && wk.ntok + total + 64 <= L.tokcap) {
                             const uint32_t jv = jump16[pos], cv = count8[pos];  // both reads in flight: one LDS round trip
                             const uint32_t j = Walk::uni(jv);
                             if (j == pos) break;  // a position the state machine has to look at
@@ -949,12 +945,21 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                             uint32_t slot = wk.ntok + segbase[lane];
                             for (uint32_t cleft = count8[pp]; cleft; cleft--) {
                                 toklist[slot++] = (uint16_t)pp;
-                                const uint32_t sv = blen[pp];
-                                pp += sv >= minp ? sv : 1u;
+                                const uint32_t sv = steps[pp];
+                                pp += LAZY ? sv : (sv >= minp ? sv : 1u);
                             }
                         }
                         wk.ntok += total;
-                        wk.rd = wk.wr = pos;
+                        if constexpr (LAZY) {
+                            wk.rd = wk.wr = pos >> 1;
+                            wk.lazy_valid = (pos & 1u) != 0;
+                            if (wk.lazy_valid) {
+                                wk.lazy_len = Walk::uni(blen2[wk.rd - 1]);
+                                wk.lazy_idx = Walk::uni(bidx2[wk.rd - 1]);
+                            }
+                        } else {
+                            wk.rd = wk.wr = pos;
+                        }
                         if (nseg) continue;
                     }
                     const uint32_t p = w_p0 + wk.rd;
@@ -1049,10 +1054,11 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                     return true;
                 }
                 uint32_t pos = e, len, idx;
-                if (LAZY) {  // position | 0x1000 (match cached by the previous step's probe) | 0x2000 (deferred: literal)
-                    pos = e & 0xFFFu;
-                    const bool cached = (e & 0x1000u) != 0;
-                    len = (e & 0x2000u) ? 0u : (cached ? (uint32_t)blen2[pos - 1] : (blen[pos] & 0x1Fu));
+                if (LAZY) {  // e = 2 * position + state; the step deferred (literal now) iff it leads to a cached state
+                    pos = e >> 1;
+                    const bool cached = (e & 1u) != 0;
+                    const bool deferred = ((e + vstep[e]) & 1u) != 0;
+                    len = deferred ? 0u : (cached ? (uint32_t)blen2[pos - 1] : (blen[pos] & 0x1Fu));
                     idx = cached ? (uint32_t)bidx2[pos - 1] : (uint32_t)bidx[pos];
                 } else {
                     len = blen[pos] & 0x1Fu, idx = bidx[pos];
