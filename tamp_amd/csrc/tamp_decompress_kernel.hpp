@@ -35,6 +35,7 @@ struct DecompressArgs {
     uint32_t dict_len;
     const uint8_t* seed_dicts;  // 3 tables of 1<<15 bytes: literal<=5, literal==6, literal>=7 (common.c:18-25)
     uint8_t* scratch;           // global variant: one window slot of (1 << max_wbits) bytes per resident lane
+    const uint32_t* order;      // optional: stream numbers to decode (a bin of the batch); null = 0..n_streams-1
     uint32_t n_streams;
     uint32_t lds_row;           // LDS variant: bytes per lane row = (1 << max_wbits) + 4
     uint8_t max_wbits;
@@ -127,7 +128,8 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
         __syncthreads();
     }
 
-    for (uint32_t s = gtid; s < a.n_streams; s += nthreads) {
+    for (uint32_t s0 = gtid; s0 < a.n_streams; s0 += nthreads) {
+        const uint32_t s = a.order ? a.order[s0] : s0;
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
         uint8_t* const out = a.out + a.out_off[s];

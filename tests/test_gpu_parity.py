@@ -546,3 +546,33 @@ def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
                     st, want, consumed = oracle.decompress(comp, dictionary=d, cap=cap, max_window_bits=10)
                     assert (int(res.status[i]), res.stream(i)) == (st, want), (mode, cap, i, len(comp))
                     assert int(res.in_consumed[i]) == consumed, (mode, cap, i)
+
+
+def test_mixed_window_binning_large_batch(ta, oracle):
+    """BASELINE config 4 at a size where the library bins the batch (>= 65,536 streams, some windows above 2^10): the
+    small-window streams go to the lane-per-stream decoder, the rest to wave-per-stream, results land in place."""
+    from tamp_amd import workloads as wl
+
+    n, L = 66560, 320
+    rows = wl.synth_text(n, L, first_index=5000)
+    wsel = np.arange(n) % 5 + 8  # windows 8..12, interleaved
+    comp = [None] * n
+    for w in range(8, 13):
+        ids = np.nonzero(wsel == w)[0]
+        sub = np.ascontiguousarray(rows[ids])
+        res = oracle.compress_batch(sub.reshape(-1), *wl.csr_for_fixed(len(ids), L), window=w, threads=16)
+        assert (res.status == 0).all()
+        for k, i in enumerate(ids):
+            comp[i] = res.stream(k)
+    comp[7] = b""           # an empty stream
+    comp[8] = comp[8][:1]   # header only
+    back = ta.decompress_batch(comp, out_cap=L + 8)  # (an exact cap ends most streams with OUTPUT_FULL, as in the reference)
+    st = np.asarray(back.status)
+    olen = np.asarray(back.out_len)
+    bad = [i for i in range(n) if i not in (7, 8) and (st[i] != 2 or back.stream(i) != rows[i].tobytes())]
+    assert not bad, bad[:10]
+    assert st[7] == 2 and olen[7] == 0 and st[8] == 2 and olen[8] == 0
+    # the limit still means what it means in the reference when the batch is binned
+    back = ta.decompress_batch(comp, out_cap=L + 8, max_window_bits=11)
+    st = np.asarray(back.status)
+    assert (st[wsel == 12] == -3).all() and (st[(wsel < 12) & (np.arange(n) > 8)] == 2).all()

@@ -32,3 +32,30 @@ run("telemetry 64Kx256 w8 l7", wl.telemetry(1<<16, 256), window=8, literal=7)
 run("text 16384x16K w10", wl.synth_text(16384, 16384))
 run("text 65536x4K w8", wl.synth_text(65536, 4096), window=8)
 run("text 16384x4K w12", wl.synth_text(16384, 4096), window=12)
+
+# BASELINE config 4 shape: windows 8..12 mixed in one batch
+def run_mixed(n, L):
+    import numpy as np
+    from oracle.checker import Oracle
+    o = Oracle()
+    rows = wl.synth_text(n, L)
+    wsel = np.arange(n) % 5 + 8
+    comp = [None] * n
+    for w in range(8, 13):
+        ids = np.nonzero(wsel == w)[0]
+        res = o.compress_batch(np.ascontiguousarray(rows[ids]).reshape(-1), *wl.csr_for_fixed(len(ids), L), window=w, threads=32)
+        for k, i in enumerate(ids): comp[i] = res.stream(k)
+    flat, off, ln = tamp_amd.pack_streams(comp) if hasattr(tamp_amd, 'pack_streams') else (None, None, None)
+    from tamp_amd.batch import pack_streams
+    flat, off, ln = pack_streams(comp)
+    d = torch.from_numpy(flat).to(dev); o_t = torch.from_numpy(off.astype(np.int64)).to(dev); l_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
+    cap = torch.full((n,), L, dtype=torch.int32, device=dev)
+    for mode in ('wave', 'auto'):
+        os.environ['TAMP_AMD_DECODER'] = mode
+        if mode == 'auto': del os.environ['TAMP_AMD_DECODER']
+        ms = []
+        for it in range(3):
+            r = tamp_amd.decompress_batch(d, o_t, l_t, out_cap=cap, timing=True); ms.append(r.kernel_ms)
+        ok = bool((r.out[:n*L].cpu().numpy() == rows.reshape(-1)).all())
+        print(f"config 4: {n}x{L} windows 8..12 {mode}: {min(ms):7.3f} ms {n*L/min(ms)/1e6:7.1f} GB/s out ok={ok}", flush=True)
+run_mixed(262144, 4096)
