@@ -134,7 +134,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": pmc_traffic_bytes(),
+            "traffic_source": "profiles/r1d_pmc_{fetch,write}_counter_collection.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "(separate passes) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) "
+                              "+ WRITE_SIZE KB; the excess over the algorithmic bytes is register-spill scratch, see DESIGN.md 3.3",
             "kernel_ms": round(k_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
             "read_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -143,7 +146,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, rows, res, np)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (profiling runs pass --no-cpu-baseline: timed loop only)
         # Not part of the metric: the same batch in the v1 format and the decode of what was just produced (round trip
         # checked), kernel time by hipEvents, for the record next to the headline number.
         try:
@@ -167,6 +170,24 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the compress kernel from the committed rocprofv3 PMC summaries (bench.py cannot run the
+    profiler on itself); None if they are missing."""
+    import csv
+
+    def mean_kb(name):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "tamp_compress" in r["Kernel_Name"]]
+        return sum(vals) / len(vals)
+
+    try:
+        fetch_kb = mean_kb("r1d_pmc_fetch_counter_collection.csv")
+        write_kb = mean_kb("r1d_pmc_write_counter_collection.csv")
+        return int(2 * fetch_kb * 1024 + write_kb * 1024)
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, rows, gpu_res, np):

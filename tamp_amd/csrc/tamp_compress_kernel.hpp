@@ -499,7 +499,8 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
     volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
     uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 64);
 
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
+    uint32_t tid = tid_k;
     const int lane = tid & (kWave - 1);
     const uint32_t wave = tid >> 6;
     const uint32_t minp = (uint32_t)min_pattern_size(a.wbits, a.lbits);
@@ -552,6 +553,9 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
         unsigned long long pc = __builtin_readcyclecounter();
 #endif
         for (;;) {
+            // (opaque re-definition: thread-indexed LDS addresses are recomputed per epoch instead of being hoisted out of
+            // the stream loop, where they would sit in -- and spill from -- registers across every phase)
+            asm volatile("" : "+v"(tid));
             const uint32_t left = n - e_p0;
             const uint32_t nvalid = left < cur_blk ? left : cur_blk;
             const uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
@@ -581,6 +585,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
 #endif
 
                 // ---------------- index: counting sort of buffer positions by bigram ----------------
+                asm volatile("" : "+v"(tid));
                 const uint32_t NE = nvalid ? W + nvalid : 0;  // positions 0..NE-1 (every query's own bigram included)
                 for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
                     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
@@ -674,6 +679,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
                 TAMP_PROF_MARK(1);
 
                 // ---------------- match: find_best_match for every position of the block ----------------
+                asm volatile("" : "+v"(tid));
                 const uint32_t nq = nvalid - e_pending;
 #ifdef TAMP_PROF
                 unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, niter = 0;
@@ -1042,6 +1048,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_kernel(CompressArgs a) {
             TAMP_PROF_MARK(3);
 
             // ---------------- emit: token list -> bits (all threads) ----------------
+            asm volatile("" : "+v"(tid));
             uint32_t act = ctl[cAct];
             const uint32_t ntok = ctl[cNtok];
             const uint32_t K = (ntok + nt - 1) / nt;
