@@ -35,8 +35,6 @@ struct DeviceCtx {
     uint8_t* scratch = nullptr;     // decoder window slots
     size_t scratch_bytes = 0;
     uint32_t* hdr_scan = nullptr;   // header pre-pass results (largest window / longest stream / bin sizes)
-    uint32_t* order = nullptr;      // decoder bins: stream numbers, small windows from the front, large from the back
-    size_t order_len = 0;
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -230,33 +228,6 @@ __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_of
     }
 }
 
-// Mixed batches (BASELINE config 4: windows 8..12 in one launch): streams whose window fits the lane-per-stream
-// decoder's LDS rows are listed from the front of `order`, the others from the back, so that each bin gets the decoder
-// that suits it.  One atomic per wave and bin.
-__global__ void tamp_header_bin_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
-                                       uint32_t split_bits, uint32_t* order, uint32_t* counts) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    bool small = false, valid = s < n;
-    uint32_t w = 0;
-    if (valid && in_len[s]) w = 8u + (in[in_off[s]] >> 5);
-    small = valid && w && w <= split_bits;
-    const uint64_t ms = __ballot(small), ml = __ballot(valid && !small);
-    uint32_t base_s = 0, base_l = 0;
-    if (lane == 0) {
-        if (ms) base_s = atomicAdd(&counts[0], (uint32_t)__builtin_popcountll(ms));
-        if (ml) base_l = atomicAdd(&counts[1], (uint32_t)__builtin_popcountll(ml));
-    }
-    base_s = (uint32_t)__shfl((int)base_s, 0), base_l = (uint32_t)__shfl((int)base_l, 0);
-    const uint64_t below = ((uint64_t)1 << lane) - 1;
-    if (small) {
-        order[base_s + (uint32_t)__builtin_popcountll(ms & below)] = s;
-        atomicMax(&counts[2], w);  // largest window of the small bin
-    } else if (valid) {
-        order[n - 1 - (base_l + (uint32_t)__builtin_popcountll(ml & below))] = s;
-    }
-}
-
 int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
                       const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                       const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
@@ -291,84 +262,37 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         if (found == 0) max_wbits = 8;
         longest_in = scan[1];
     }
-    a.order = nullptr;
-    const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" (tuning / tests)
-    if (!exact && !force && longest_in != 0xFFFFFFFFu && max_wbits > kLdsWinBits && max_wbits <= 15 &&
-        n_streams >= 65536) {
-        // some windows are too large for LDS rows: decode the small-window streams with lanes, the rest with waves
-        {
-            std::lock_guard<std::mutex> lock(g_mu);
-            if (ctx->order_len < n_streams) {
-                if (ctx->order) {
-                    HIP_OK(hipDeviceSynchronize());
-                    HIP_OK(hipFree(ctx->order));
-                    ctx->order = nullptr;
-                    ctx->order_len = 0;
-                }
-                HIP_OK(hipMalloc(&ctx->order, n_streams * sizeof(uint32_t)));
-                ctx->order_len = n_streams;
-            }
-        }
-        uint32_t bins[3] = {0, 0, 0};
-        HIP_OK(hipMemsetAsync(ctx->hdr_scan + 2, 0, 12, st));
-        hipLaunchKernelGGL(tamp_header_bin_kernel, dim3((uint32_t)((n_streams + 255) / 256)), dim3(256), 0, st, d_in, d_in_off,
-                           d_in_len, (uint32_t)n_streams, kLdsWinBits, ctx->order, ctx->hdr_scan + 2);
-        HIP_OK(hipMemcpyAsync(bins, ctx->hdr_scan + 2, 12, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        const size_t n_small = bins[0], n_large = bins[1];
-        const uint8_t small_bits = (uint8_t)(bins[2] >= 8 ? bins[2] : 8);
-        const uint32_t lds = lane_decoder_lds(small_bits);
-        const size_t capacity = (size_t)ctx->cu_count * std::min<size_t>(160 * 1024 / lds, 16) * kWave;
-        if (n_small + n_large == n_streams && n_small * 10 >= ((n_small + capacity - 1) / capacity) * capacity * 6) {
-            timing_begin(st);
-            {   // small windows: lane per stream, bulk build
-                DecompressArgs b = a;
-                b.order = ctx->order, b.n_streams = (uint32_t)n_small, b.max_wbits = small_bits;
-                b.lds_row = (1u << small_bits) + kLaneRowPad;
-                size_t groups = (n_small + kWave - 1) / kWave;
-                const size_t resident = (size_t)ctx->cu_count * std::min<size_t>(160 * 1024 / lds, 16);
-                if (groups > resident * 4) groups = resident * 4;
-                auto lane_kernel = tamp_decompress_kernel<true, true>;
-                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(lane_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(lane_kernel, dim3((uint32_t)groups), dim3(kWave), lds, st, b);
-            }
-            if (n_large) {  // the rest (larger windows, empty streams): wave per stream
-                DecompressArgs b = a;
-                b.order = ctx->order + n_small, b.n_streams = (uint32_t)n_large, b.max_wbits = max_wbits;
-                const uint32_t waves = max_wbits <= 12 ? 4 : 1;
-                const uint32_t wlds = decode_wave_lds(max_wbits, waves);
-                size_t groups = (n_large + waves - 1) / waves;
-                const size_t resident = (size_t)ctx->cu_count * 64;
-                if (groups > resident) groups = resident;
-                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_wave_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-                hipLaunchKernelGGL(tamp_decompress_wave_kernel, dim3((uint32_t)groups), dim3(waves * kWave), wlds, st, b);
-            }
-            timing_end(st);
-            HIP_OK(hipGetLastError());
-            return TAMP_OK;
-        }
-    }
+    const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" | "global" (tuning / tests)
     a.max_wbits = max_wbits;
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
     // Decoder choice: one wavefront per stream (scalar token loop, window in LDS, 64-lane copies) unless the batch is
     // a very large number of streams, where one lane per stream fills the chip and avoids per-stream set-up.
-    // Lane-per-stream works in rounds of `capacity` streams (LDS rows limit the resident lanes) and a round lasts as long
-    // as its longest stream; per byte it is about twice as fast as wave-per-stream, whose time follows the total bytes.
-    // So: lanes when the rounds are at least ~60 % full.
+    // Three decoders.  Wave per stream: time follows the total bytes, needs few streams.  Lane per
+    // stream with the windows in LDS: rounds of `capacity` streams (the rows limit the resident lanes), a round lasts as
+    // long as its longest stream, about twice as fast per byte -- taken when a single round is reasonably full, and for
+    // batches of short messages.  Lane per stream with the windows in a global scratch slab: no capacity limit, every
+    // wave resident at once and the memory latency hidden by the other waves of the SIMD -- taken for large batches of
+    // long streams, whatever their windows (mixed-window batches included).
     const bool bulk = longest_in >= 512;  // short messages: the lean lane build (no bulk path, smaller rows)
-    bool lanes_pay = false;
-    if (valid_bits && max_wbits <= kLdsWinBits) {
-        const uint32_t lds = bulk ? lane_decoder_lds(max_wbits) : kWave * ((1u << max_wbits) + 4);
-        const size_t per_cu = std::min<size_t>(160 * 1024 / lds, 16);
-        const size_t capacity = (size_t)ctx->cu_count * per_cu * kWave;
-        const size_t rounds = (n_streams + capacity - 1) / capacity;
-        // (short messages: a round is over so quickly that even a quarter-full one beats the wave decoder)
-        lanes_pay = n_streams * 10 >= rounds * capacity * (bulk ? 6 : 2);
+    const bool force_global = force && force[0] == 'g';
+    bool lds_lanes = false, global_lanes = false;
+    if (valid_bits) {
+        size_t capacity = 0;
+        if (max_wbits <= kLdsWinBits) {
+            const uint32_t lds = bulk ? lane_decoder_lds(max_wbits) : kWave * ((1u << max_wbits) + 4);
+            capacity = (size_t)ctx->cu_count * std::min<size_t>(160 * 1024 / lds, 16) * kWave;
+        }
+        if (!bulk) {
+            const size_t rounds = capacity ? (n_streams + capacity - 1) / capacity : 1;
+            lds_lanes = capacity && n_streams * 10 >= rounds * capacity * 2;
+        } else {
+            lds_lanes = capacity && n_streams * 10 >= capacity * 6 && n_streams * 4 <= capacity * 5;
+            global_lanes = !lds_lanes && n_streams >= (size_t)ctx->cu_count * 192;  // ~3/4 wave per SIMD and up
+        }
     }
-    const bool use_wave = force ? (force[0] == 'w') : !lanes_pay;
+    if (force) lds_lanes = force[0] == 'l', global_lanes = force_global;
+    const bool use_wave = force ? (force[0] == 'w') : !(lds_lanes || global_lanes);
     if (valid_bits && use_wave) {
         const uint32_t waves = max_wbits <= 12 ? 4 : 1;
         const uint32_t lds = decode_wave_lds(max_wbits, waves);
@@ -383,7 +307,7 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         HIP_OK(hipGetLastError());
         return TAMP_OK;
     }
-    if (valid_bits && max_wbits <= kLdsWinBits) {
+    if (valid_bits && max_wbits <= kLdsWinBits && !global_lanes) {
         // windows in LDS: one 64-lane workgroup per 64 streams, one padded row per lane
         a.lds_row = (1u << max_wbits) + (bulk ? kLaneRowPad : 4u);
         const uint32_t lds = bulk ? lane_decoder_lds(max_wbits) : kWave * a.lds_row;
@@ -402,7 +326,9 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     }
     const uint32_t threads = 256;
     const uint8_t slot_bits = valid_bits ? max_wbits : 8;
-    const size_t slot = (size_t)1 << slot_bits;
+    const bool gbulk = valid_bits && bulk;  // bulk path with the windows in the scratch slab (slots padded like LDS rows)
+    const size_t slot = ((size_t)1 << slot_bits) + (gbulk ? 64 : 0);
+    a.lds_row = (uint32_t)slot;
     // resident lanes: enough to fill the chip, bounded by a 1 GiB window slab
     size_t lanes = (size_t)ctx->cu_count * 2048;
     const size_t budget = (size_t)1 << 30;
@@ -425,7 +351,10 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     }
     a.scratch = ctx->scratch;
     timing_begin(st);
-    hipLaunchKernelGGL((tamp_decompress_kernel<false, false>), dim3(grid), dim3(threads), 0, st, a);
+    if (gbulk)
+        hipLaunchKernelGGL((tamp_decompress_kernel<false, true>), dim3(grid), dim3(threads), 128 + threads * kLaneStagePad, st, a);
+    else
+        hipLaunchKernelGGL((tamp_decompress_kernel<false, false>), dim3(grid), dim3(threads), 0, st, a);
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;

@@ -35,7 +35,6 @@ struct DecompressArgs {
     uint32_t dict_len;
     const uint8_t* seed_dicts;  // 3 tables of 1<<15 bytes: literal<=5, literal==6, literal>=7 (common.c:18-25)
     uint8_t* scratch;           // global variant: one window slot of (1 << max_wbits) bytes per resident lane
-    const uint32_t* order;      // optional: stream numbers to decode (a bin of the batch); null = 0..n_streams-1
     uint32_t n_streams;
     uint32_t lds_row;           // LDS variant: bytes per lane row = (1 << max_wbits) + 4
     uint8_t max_wbits;
@@ -99,19 +98,19 @@ __device__ __forceinline__ int read_symbol(uint32_t b, uint32_t avail, uint32_t&
     return sym;
 }
 
-// LDSWIN: window rows in LDS (else per-lane slots of a global scratch slab).  BULK (LDS variant only): the straight-line
+// LDSWIN: window rows in LDS (else per-lane slots of a global scratch slab).  BULK: the straight-line
 // bulk path with its LUT / output stage / row slack is compiled in; batches of short messages take the lean build,
 // which fits more workgroups on a CU.
 template <bool LDSWIN, bool BULK = false>
 __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(DecompressArgs a) {
-    static_assert(LDSWIN || !BULK, "the bulk path needs the window in LDS");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    uint8_t* const lut = smem;                                         // LDS variant only
-    uint8_t* const stg = smem + 128 + threadIdx.x * kLaneStagePad;      // LDS variant only
+    uint8_t* const lut = smem;                                         // bulk builds only
+    uint8_t* const stg = smem + 128 + threadIdx.x * kLaneStagePad;      // bulk builds only
+    // window: an LDS row per lane, or a slot of the global scratch slab (bulk builds: slot stride a.lds_row, padded)
     uint8_t* const win = LDSWIN ? smem + (BULK ? 128 + kWave * kLaneStagePad : 0u) + threadIdx.x * a.lds_row
-                                : a.scratch + ((size_t)gtid << a.max_wbits);
+                                : a.scratch + (BULK ? (size_t)gtid * a.lds_row : ((size_t)gtid << a.max_wbits));
     if constexpr (BULK) {
         // prefix-code LUT: index = the 7 bits after the leading 1 of a code word -> (extra bits << 4) | symbol
         // (decompressor.c:52-57 restated from the code table, compressor.c:33-36)
@@ -128,8 +127,7 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
         __syncthreads();
     }
 
-    for (uint32_t s0 = gtid; s0 < a.n_streams; s0 += nthreads) {
-        const uint32_t s = a.order ? a.order[s0] : s0;
+    for (uint32_t s = gtid; s < a.n_streams; s += nthreads) {
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
         uint8_t* const out = a.out + a.out_off[s];

@@ -49,8 +49,7 @@ __global__ void __launch_bounds__(256) tamp_decompress_wave_kernel(DecompressArg
     __syncthreads();
 
     const uint32_t gw = blockIdx.x * nwaves + wave, tw = gridDim.x * nwaves;
-    for (uint32_t s0 = gw; s0 < a.n_streams; s0 += tw) {
-        const uint32_t s = a.order ? uni32(a.order[s0]) : s0;
+    for (uint32_t s = gw; s < a.n_streams; s += tw) {
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
         uint8_t* const out = a.out + a.out_off[s];

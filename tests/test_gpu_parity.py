@@ -511,7 +511,8 @@ def test_mixed_window_batch_and_header_prepass(ta, oracle):
 
 
 def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
-    """All three decoders (wave per stream; lane per stream lean / bulk build) on streams long enough for the bulk path:
+    """All decoders (wave per stream; lane per stream with LDS windows, lean / bulk build; lane per stream with the
+    windows in the global scratch slab) on streams long enough for the bulk path:
     plain, extended (RLE + extended-match tokens), custom dictionary, FLUSH / dictionary_reset streams, truncated
     input and restricted output -- status, length, bytes and consumed counts against the oracle."""
     from tamp_amd import workloads as wl
@@ -536,7 +537,7 @@ def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
     # truncated inputs
     for comp, d in list(cases[:12]):
         cases.append((comp[: rng.randrange(40, len(comp))], d))
-    for mode in ("wave", "lane"):
+    for mode in ("wave", "lane", "global"):
         monkeypatch.setenv("TAMP_AMD_DECODER", mode)
         for d in (None, d10):
             group = [c for c, dd in cases if dd is d]
@@ -549,8 +550,8 @@ def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
 
 
 def test_mixed_window_binning_large_batch(ta, oracle):
-    """BASELINE config 4 at a size where the library bins the batch (>= 65,536 streams, some windows above 2^10): the
-    small-window streams go to the lane-per-stream decoder, the rest to wave-per-stream, results land in place."""
+    """BASELINE config 4 at a size where the library picks the lane-per-stream decoder with global-memory windows
+    (>= 49,152 streams, some windows above 2^10): every window size in one launch."""
     from tamp_amd import workloads as wl
 
     n, L = 66560, 320

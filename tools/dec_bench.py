@@ -14,7 +14,7 @@ def run(name, rows, **kw):
     data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
     r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=L, **kw)
     cap = torch.full((n,), L, dtype=torch.int32, device=dev)
-    for mode in ('wave', 'lane', 'auto'):
+    for mode in ('wave', 'lane', 'global', 'auto'):
         os.environ['TAMP_AMD_DECODER'] = mode
         if mode == 'auto': del os.environ['TAMP_AMD_DECODER']
         ms = []
@@ -23,9 +23,10 @@ def run(name, rows, **kw):
             ms.append(d.kernel_ms)
         ok = bool((d.out[:n*L].cpu().numpy() == rows.reshape(-1)).all())
         print(f"{name:26s} {mode}: {min(ms):7.3f} ms  {n*L/min(ms)/1e6:7.1f} GB/s out  ok={ok}", flush=True)
-for nn in (2048, 8192, 16384, 32768):
+for nn in (16384,):
     run(f"text {nn}x4K w10 ext", wl.synth_text(nn, 4096))
 run("text 65536x4K w10 ext", wl.synth_text(65536, 4096))
+run("text 262144x4K w10 ext", wl.synth_text(262144, 4096))
 run("text 65536x4K w10 v1", wl.synth_text(65536, 4096), extended=False)
 run("telemetry 1Mx256 w8 l7", wl.telemetry(1<<20, 256), window=8, literal=7)
 run("telemetry 64Kx256 w8 l7", wl.telemetry(1<<16, 256), window=8, literal=7)
@@ -50,7 +51,7 @@ def run_mixed(n, L):
     flat, off, ln = pack_streams(comp)
     d = torch.from_numpy(flat).to(dev); o_t = torch.from_numpy(off.astype(np.int64)).to(dev); l_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
     cap = torch.full((n,), L, dtype=torch.int32, device=dev)
-    for mode in ('wave', 'auto'):
+    for mode in ('wave', 'global', 'auto'):
         os.environ['TAMP_AMD_DECODER'] = mode
         if mode == 'auto': del os.environ['TAMP_AMD_DECODER']
         ms = []
