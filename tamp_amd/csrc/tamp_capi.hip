@@ -212,19 +212,25 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
 // streams would otherwise run at a fraction of the occupancy.
 __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                         uint32_t limit, uint32_t* result) {
-    uint32_t m = 0, longest = 0;
+    uint32_t m = 0, longest = 0, wsum = 0;  // wsum: window bytes / 256, summed over the streams within the limit
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const uint32_t len = in_len[s];
         if (len == 0) continue;
         longest = len > longest ? len : longest;
         const uint32_t w = 8u + (in[in_off[s]] >> 5);  // header byte, decompressor.c:276-297
-        if (w <= limit && w > m) m = w;
+        if (w <= limit) {
+            m = w > m ? w : m;
+            wsum += 1u << (w - 8);
+        }
     }
     m = wave_max_u32(m);
     longest = wave_max_u32(longest);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, off);
     if ((threadIdx.x & (kWave - 1)) == 0) {
         if (m) atomicMax(result, m);
         atomicMax(result + 1, longest);
+        atomicAdd(result + 2, wsum);
     }
 }
 
@@ -243,24 +249,26 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.n_streams = (uint32_t)n_streams;
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
     uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)
+    uint64_t window_bytes = 0;          // sum of the streams' window sizes (0 = unknown)
     max_wbits &= 0x7F;
     if (!exact && max_wbits > 8 && max_wbits <= 15 && n_streams >= 256) {
         {
             std::lock_guard<std::mutex> lock(g_mu);
             if (!ctx->hdr_scan) HIP_OK(hipMalloc(&ctx->hdr_scan, 32));
         }
-        uint32_t scan[2] = {0, 0};
+        uint32_t scan[3] = {0, 0, 0};
         uint32_t& found = scan[0];
-        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 8, st));
+        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 12, st));
         const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
         hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, (uint32_t)n_streams,
                            (uint32_t)max_wbits, ctx->hdr_scan);
-        HIP_OK(hipMemcpyAsync(scan, ctx->hdr_scan, 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(scan, ctx->hdr_scan, 12, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         // streams above the limit fail with TAMP_INVALID_CONF under either value; nothing valid exceeds `found`
         if (found >= 8 && found < max_wbits) max_wbits = (uint8_t)found;
         if (found == 0) max_wbits = 8;
         longest_in = scan[1];
+        window_bytes = (uint64_t)scan[2] << 8;
     }
     const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" | "global" (tuning / tests)
     a.max_wbits = max_wbits;
@@ -286,6 +294,10 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         if (!bulk) {
             const size_t rounds = capacity ? (n_streams + capacity - 1) / capacity : 1;
             lds_lanes = capacity && n_streams * 10 >= rounds * capacity * 2;
+        } else if (capacity && max_wbits <= 9) {
+            // small windows: four and more waves of rows fit a CU's LDS, nothing beats that
+            const size_t rounds = (n_streams + capacity - 1) / capacity;
+            lds_lanes = n_streams * 10 >= rounds * capacity * 6;
         } else {
             lds_lanes = capacity && n_streams * 10 >= capacity * 6 && n_streams * 4 <= capacity * 5;
             global_lanes = !lds_lanes && n_streams >= (size_t)ctx->cu_count * 192;  // ~3/4 wave per SIMD and up
@@ -329,9 +341,17 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     const bool gbulk = valid_bits && bulk;  // bulk path with the windows in the scratch slab (slots padded like LDS rows)
     const size_t slot = ((size_t)1 << slot_bits) + (gbulk ? 64 : 0);
     a.lds_row = (uint32_t)slot;
-    // resident lanes: enough to fill the chip, bounded by a 1 GiB window slab
+    // Resident lanes.  Every step touches the lane's window at random: the kernel runs at the speed of the Infinity
+    // Cache (256 MB) as long as the windows in flight fit into it, and of HBM sector traffic beyond.  So: as many lanes
+    // as ~144 MB of live windows allow, but at least one wave per SIMD (and no more than eight).
     size_t lanes = (size_t)ctx->cu_count * 2048;
-    const size_t budget = (size_t)1 << 30;
+    {
+        const size_t avg_window = window_bytes ? std::max<size_t>(256, (size_t)(window_bytes / n_streams)) : ((size_t)1 << slot_bits);
+        size_t fit = ((size_t)144 << 20) / avg_window;
+        if (const char* e = getenv("TAMP_AMD_SCRATCH_MB")) fit = ((size_t)atoi(e) << 20) / avg_window;  // tuning
+        lanes = std::min(lanes, std::max(fit, (size_t)ctx->cu_count * 256));
+    }
+    const size_t budget = (size_t)4 << 30;  // hard bound of the slab
     if (lanes * slot > budget) lanes = budget / slot;
     if (lanes > n_streams) lanes = n_streams;
     const uint32_t grid = (uint32_t)((lanes + threads - 1) / threads);
