@@ -10,6 +10,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -32,9 +33,14 @@ struct DeviceCtx {
     int cu_count = 0;
     size_t lds_per_block = 0;
     uint8_t* seed_dicts = nullptr;  // 3 x 32 KiB: literal<=5, ==6, >=7
-    uint8_t* scratch = nullptr;     // decoder window slots
-    size_t scratch_bytes = 0;
-    uint32_t* hdr_scan = nullptr;   // header pre-pass results (largest window / longest stream / bin sizes)
+    // decoder window slabs, one per HIP stream that ever needed one: launches on one stream are ordered and may share
+    // a slab, launches on different streams run concurrently and may not
+    struct Slab {
+        uint8_t* p = nullptr;
+        size_t bytes = 0;
+        uint32_t* scan = nullptr;  // header pre-pass results (largest window / longest stream / window bytes)
+    };
+    std::map<hipStream_t, Slab> slabs;
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -252,17 +258,20 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     uint64_t window_bytes = 0;          // sum of the streams' window sizes (0 = unknown)
     max_wbits &= 0x7F;
     if (!exact && max_wbits > 8 && max_wbits <= 15 && n_streams >= 256) {
+        uint32_t* hdr_scan = nullptr;
         {
             std::lock_guard<std::mutex> lock(g_mu);
-            if (!ctx->hdr_scan) HIP_OK(hipMalloc(&ctx->hdr_scan, 32));
+            DeviceCtx::Slab& slab = ctx->slabs[st];
+            if (!slab.scan) HIP_OK(hipMalloc(&slab.scan, 32));
+            hdr_scan = slab.scan;
         }
         uint32_t scan[3] = {0, 0, 0};
         uint32_t& found = scan[0];
-        HIP_OK(hipMemsetAsync(ctx->hdr_scan, 0, 12, st));
+        HIP_OK(hipMemsetAsync(hdr_scan, 0, 12, st));
         const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
         hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, (uint32_t)n_streams,
-                           (uint32_t)max_wbits, ctx->hdr_scan);
-        HIP_OK(hipMemcpyAsync(scan, ctx->hdr_scan, 12, hipMemcpyDeviceToHost, st));
+                           (uint32_t)max_wbits, hdr_scan);
+        HIP_OK(hipMemcpyAsync(scan, hdr_scan, 12, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         // streams above the limit fail with TAMP_INVALID_CONF under either value; nothing valid exceeds `found`
         if (found >= 8 && found < max_wbits) max_wbits = (uint8_t)found;
@@ -358,18 +367,19 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     const size_t need = (size_t)grid * threads * slot;
     {
         std::lock_guard<std::mutex> lock(g_mu);
-        if (ctx->scratch_bytes < need) {
-            if (ctx->scratch) {
-                HIP_OK(hipDeviceSynchronize());
-                HIP_OK(hipFree(ctx->scratch));
-                ctx->scratch = nullptr;
-                ctx->scratch_bytes = 0;
+        DeviceCtx::Slab& slab = ctx->slabs[st];
+        if (slab.bytes < need) {
+            if (slab.p) {
+                HIP_OK(hipStreamSynchronize(st));  // earlier launches on this stream still use the old slab
+                HIP_OK(hipFree(slab.p));
+                slab.p = nullptr;
+                slab.bytes = 0;
             }
-            HIP_OK(hipMalloc(&ctx->scratch, need));
-            ctx->scratch_bytes = need;
+            HIP_OK(hipMalloc(&slab.p, need));
+            slab.bytes = need;
         }
+        a.scratch = slab.p;
     }
-    a.scratch = ctx->scratch;
     timing_begin(st);
     if (gbulk)
         hipLaunchKernelGGL((tamp_decompress_kernel<false, true>), dim3(grid), dim3(threads), 128 + threads * kLaneStagePad, st, a);

@@ -577,3 +577,33 @@ def test_mixed_window_binning_large_batch(ta, oracle):
     back = ta.decompress_batch(comp, out_cap=L + 8, max_window_bits=11)
     st = np.asarray(back.status)
     assert (st[wsel == 12] == -3).all() and (st[(wsel < 12) & (np.arange(n) > 8)] == 2).all()
+
+
+def test_concurrent_streams_do_not_share_decoder_scratch(ta, monkeypatch):
+    """Two decode calls in flight on two HIP streams (global-window decoder: per-lane window slots in a scratch slab):
+    each stream owns its slab, so neither corrupts the other's windows."""
+    import torch
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("TAMP_AMD_DECODER", "global")
+    jobs = []
+    for k, w in enumerate((10, 12)):
+        n, L = 20000, 2048
+        rows = wl.synth_text(n, L, first_index=70000 * (k + 1))
+        off, ln = wl.csr_for_fixed(n, L)
+        data = torch.from_numpy(rows.reshape(-1)).to(dev)
+        r = ta.compress_batch(data, torch.from_numpy(off.astype(np.int64)).to(dev), torch.from_numpy(ln.astype(np.int32)).to(dev),
+                              window=w, max_in_len=L)
+        jobs.append((torch.cuda.Stream(dev), r, data, n, L))
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):  # launches alternate between the two streams and overlap on the device
+        for s, r, data, n, L in jobs:
+            with torch.cuda.stream(s):
+                outs.append((ta.decompress_batch(r.out, r.out_off, r.out_len, out_cap=L + 8, scan_headers=False), data, n, L))
+    torch.cuda.synchronize()
+    for back, data, n, L in outs:
+        assert bool((back.out_len == L).all().item())
+        got = back.out[: n * (L + 8)].view(n, L + 8)[:, :L].reshape(-1)
+        assert torch.equal(got, data)
