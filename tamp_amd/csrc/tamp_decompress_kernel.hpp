@@ -45,7 +45,10 @@ constexpr uint32_t kLdsWinBits = 10;  // largest window kept in LDS: 64 lanes x 
 // (1 << max_wbits) + 36 bytes: 32 bytes of slack behind the window (16 that mirror its first bytes when a write runs
 // over the end, 16 so that 16-byte reads near the end stay inside the row) + 4 so that the row stride in dwords is odd
 // (lanes touching the same index hit different banks).
-constexpr uint32_t kLaneRowPad = 36, kLaneStagePad = 84;  // stage: 4 pieces of 16 B + 15 carried bytes, odd dword stride
+constexpr uint32_t kLaneRowPad = 36;
+// per-lane staging in bulk builds: 80 B of output (4 pieces of 16 B + 15 carried bytes) + a 64 B ring of input; 148 B
+// = 37 dwords, an odd stride
+constexpr uint32_t kLaneStagePad = 148, kLaneInRing = 64, kLaneInOff = 84;
 __host__ __device__ constexpr uint32_t lane_decoder_lds(uint32_t max_wbits) {
     return 128u + kWave * kLaneStagePad + kWave * ((1u << max_wbits) + kLaneRowPad);
 }
@@ -237,27 +240,32 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                 first_pass = false;
                 filled = W;
                 uint32_t T = 8 * ip - nb;  // bits consumed from the start of the stream
-                uint32_t sp = T >> 3, si = 0;  // input chunks [sp, sp+16) and [sp+16, sp+32); si: next dword of `ca`
+                const uint32_t sp = T >> 3;  // stream offset of the byte holding the next bit
                 bool fast = sp + 32 <= n && cap - op >= 16;
-                // Input pipeline: `ca` is being consumed, `cn` is the next 16 bytes (complete), `cb` is in flight.  Global
-                // loads and stores are issued only at the I/O points below (every 4th step, the same step for all 64
-                // lanes) and what they fetch is first touched at the next I/O point: stores share the vector-memory
-                // counter with loads on gfx9, so a wait inside the step code would sit out every store latency.
-                B16 ca = {{0, 0, 0, 0}}, cn = {{0, 0, 0, 0}}, cb = {{0, 0, 0, 0}};
-                bool cn_valid = false, cb_valid = false;
-                uint32_t ld_off = sp + 16;  // next chunk to fetch
+                // Input pipeline: compressed bytes pass through a 64-byte ring per lane in LDS.  A 16-byte chunk is fetched
+                // from HBM into registers at one I/O point (every 4th step, the same step for all 64 lanes), stored to the
+                // ring at the next one, and read from there a dword at a time (one dword prefetched).  Global loads and
+                // stores are thus issued, and their results first touched, only at I/O points: stores share the
+                // vector-memory counter with loads on gfx9, and a wait inside the step code would sit out every store.
+                uint8_t* const inr = stg + kLaneInOff;
+                const uint32_t sp0 = sp;  // stream byte x lives at inr[(x - sp0) & 63]
+                auto ring_u32 = [&](uint32_t x) { return *reinterpret_cast<const uint32_t*>(inr + ((x - sp0) & (kLaneInRing - 1))); };
+                B16 cb = {{0, 0, 0, 0}};  // chunk in flight
+                bool cb_valid = false;
+                uint32_t rp = sp;      // stream offset of the dword held in `wnext`
+                uint32_t fill = sp;    // the ring holds stream bytes [.., fill)
+                uint32_t ld_off = sp;  // next chunk to fetch
+                uint32_t wnext = 0;
                 uint64_t fb = 0;  // upcoming bits, left aligned
                 uint32_t fn = 0;  // valid bits in fb
                 if (fast) {
-                    cb = ld16(in + sp);
-                    ca = cb;
-                    cb = ld16(in + sp + 16);
-                    cn = cb;
-                    cn_valid = true;
-                    ld_off = sp + 32;
-                    fb = (uint64_t)__builtin_bswap32(ca.w[0]) << (32 + (T & 7));  // first dword, bits before T dropped
+                    st16(inr, ld16(in + sp));
+                    st16(inr + 16, ld16(in + sp + 16));
+                    fill = ld_off = sp + 32;
+                    fb = (uint64_t)__builtin_bswap32(ring_u32(sp)) << (32 + (T & 7));  // first dword, bits before T dropped
                     fn = 32 - (T & 7);
-                    si = 1;
+                    rp = sp + 4;
+                    wnext = ring_u32(rp);
                     budget = 2;
                 }
                 const uint32_t T_in = T;
@@ -265,17 +273,11 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                 uint32_t on16 = 0, obase = op;  // bytes in the output stage; bytes already stored
                 uint32_t pend = 0, p_w = 0, p_off = 0, p_kind = 0, p_byte = 0;  // rest of a token longer than 16 bytes
                 auto refill32 = [&]() -> bool {
-                    if (si == 4) {
-                        if (!cn_valid) return false;  // the pipeline ran dry (a streak of long tokens, or the end of the input)
-                        ca = cn;
-                        cn_valid = false;
-                        sp += 16;
-                        si = 0;
-                    }
-                    const uint32_t w = si == 0 ? ca.w[0] : (si == 1 ? ca.w[1] : (si == 2 ? ca.w[2] : ca.w[3]));
-                    fb |= (uint64_t)__builtin_bswap32(w) << (32 - fn);
+                    if (rp + 4 > fill) return false;  // the ring ran dry (a streak of long tokens, or the end of the input)
+                    fb |= (uint64_t)__builtin_bswap32(wnext) << (32 - fn);
                     fn += 32;
-                    si++;
+                    rp += 4;
+                    wnext = ring_u32(rp);  // (may be a stale slot: it is not used before `fill` has passed it)
                     return true;
                 };
                 auto flush_blocks = [&]() {  // whole 16-byte blocks of the stage -> HBM, the rest moves to the front
@@ -294,9 +296,10 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                     if ((step++ & 3) == 0) {  // ---- I/O point ----
                         flush_blocks();
                         if (fast) {
-                            if (cb_valid && !cn_valid) {
-                                cn = cb;
-                                cn_valid = true;
+                            if (cb_valid && fill + 16 - (rp - 4) <= kLaneInRing) {  // room: the oldest live dword is at rp - 4
+                                st16(inr + ((fill - sp0) & (kLaneInRing - 1)), cb);
+                                if (fill == rp) wnext = cb.w[0];  // the prefetched dword was read before this chunk arrived
+                                fill += 16;
                                 cb_valid = false;
                             }
                             if (!cb_valid && ld_off + 16 <= n) {
