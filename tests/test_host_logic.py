@@ -92,3 +92,32 @@ def test_partition_streams():
     off = np.concatenate([[0], np.cumsum(lens)[:-1]])
     b, e, lo, hi = sharding.shard_for_rank(off, lens, 1, 4)
     assert lo == int(off[b]) and hi == int(off[e - 1] + lens[e - 1])
+
+
+def test_header_constants_match_python_side():
+    """Flags that cross the ctypes boundary by value: the header is the source of truth."""
+    import os
+    import re
+
+    from tamp_amd import _lib
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tamp_amd.h")).read()
+    m = re.search(r"#define\s+TAMP_AMD_WINDOW_BITS_EXACT\s+(0x[0-9a-fA-F]+)", hdr)
+    assert m and int(m.group(1), 16) == _lib.WINDOW_BITS_EXACT
+    for name, val in (("TAMP_AMD_MEM_HOST", _lib.MEM_HOST), ("TAMP_AMD_MEM_DEVICE", _lib.MEM_DEVICE),
+                      ("TAMP_AMD_NO_DEVICE", _lib.NO_DEVICE), ("TAMP_AMD_BAD_ARGUMENT", _lib.BAD_ARGUMENT)):
+        m = re.search(name + r"\s*=\s*(-?\d+)", hdr)
+        assert m and int(m.group(1)) == val, name
+
+
+def test_bench_reads_committed_pmc_summaries():
+    """bench.py's roofline.traffic comes from the PMC passes committed under profiles/ (FETCH x2 + WRITE, in bytes)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    t = mod.pmc_traffic_bytes()
+    assert t is not None and 3e8 < t < 1e11  # at least the 268 MB of input; not absurd
