@@ -7,15 +7,18 @@
 // (SURVEY.md H5), so parallelism is across streams: 64 independent streams per wavefront, each lane
 // running the reference's token loop on its own bit buffer.
 //
-//   * Windows up to 2^10 bytes live in LDS (one padded 1028-byte row per lane, conflict-free when the lanes
-//     touch the same index and spread over the banks otherwise): every back-reference byte is an LDS access
-//     instead of a divergent global one.  Larger windows (or mixed batches up to 2^15) use a per-lane slot of
-//     a global scratch slab that stays L2 / MALL resident.
-//   * A window slot that has not been written yet reads straight from the shared seed (or custom) dictionary,
-//     so no per-stream dictionary copy is made.
-//   * Compressed input is prefetched a dword at a time and output is written as aligned dwords; the logical
-//     byte-by-byte refill of the reference (which decides status and consumed counts on truncated input) is
-//     reproduced on top of that.
+// Template parameters pick one of three builds:
+//   <true,  false>  windows in LDS rows, only the reference-shaped ("exact") token loop: batches of short messages;
+//   <true,  true>   windows in LDS rows (<= 2^10 bytes) + the straight-line bulk path in front of the exact loop;
+//   <false, true>   the same bulk path with the window in a per-lane slot of a global scratch slab (any window size,
+//                   any number of resident waves);  <false, false> is the slab variant without the bulk path.
+//
+//   * Exact loop: the reference's token loop, byte-wise refill included (it decides status and consumed counts on
+//     truncated input); a window slot that has not been written yet reads straight from the shared seed / custom
+//     dictionary; input is prefetched a dword at a time, output leaves as aligned dwords.
+//   * Bulk path: one token (or one 16-byte piece of a long one) per lane and step, straight-line code; 16-byte window
+//     and output moves; input through a 64-byte LDS ring; global loads / stores only at I/O points common to the wave.
+//     It ends at a token boundary whenever something needs the exact loop, which then resumes from the bit position.
 #pragma once
 #include "tamp_common.hpp"
 
