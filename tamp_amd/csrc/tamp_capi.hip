@@ -151,8 +151,11 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy) {
     uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
     if (blk > 2048) blk = 2048;
     if (blk > 1536) {
-        const uint32_t lds_cu = 160u * 1024u;
-        if (lds_cu / CompressLds(W, 1536, packed, lazy).total > lds_cu / CompressLds(W, blk, packed, lazy).total) blk = 1536;
+        // (LDS is handed out in coarse granules: 26,960 B per workgroup measured as five per CU, 25,424 B as six)
+        const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
+        if (lds_cu / align_up(CompressLds(W, 1536, packed, lazy).total, granule) >
+            lds_cu / align_up(CompressLds(W, blk, packed, lazy).total, granule))
+            blk = 1536;
     }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;
