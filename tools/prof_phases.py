@@ -22,13 +22,17 @@ if WL.startswith('glob:'):
     rows = np.frombuffer(bytes(blob[:k*4096]), dtype=np.uint8).reshape(k, 4096)
     rows = np.tile(rows, ((n + k - 1) // k, 1))[:n].copy()
 else:
-    rows = getattr(wl, WL)(n, 4096)
-off, ln = wl.csr_for_fixed(n, 4096)
+    rows = getattr(wl, WL)(n, int(os.environ.get('SLEN', '4096')))
+SLEN = rows.shape[1]
+off, ln = wl.csr_for_fixed(n, SLEN)
+CONF = dict(window=int(os.environ.get('WINDOW', '10')), literal=int(os.environ.get('LITERAL', '8')))
+if os.environ.get('TELDICT'):
+    CONF['dictionary'] = wl.telemetry_dictionary(bytes(tamp_amd.initialize_dictionary(256, literal=7)))
 dev = torch.device('cuda:0')
 data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
 for ext in (1, 0):
     for it in range(2):
-        r = tamp_amd.compress_batch(data, off_t, len_t, extended=bool(ext), max_in_len=4096, timing=True)
+        r = tamp_amd.compress_batch(data, off_t, len_t, extended=bool(ext), max_in_len=SLEN, timing=True, **CONF)
         torch.cuda.synchronize()
         lib.tamp_amd_prof_read(buf)
     v = np.array(list(buf), dtype=np.float64) / n
