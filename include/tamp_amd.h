@@ -46,15 +46,22 @@ typedef struct TampAmdConf {
     uint8_t use_custom_dictionary; /* `dictionary` argument holds 1<<window bytes shared by all streams */
     uint8_t extended;              /* library default of the reference is 1 (compressor.c:193-203) */
     uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
-    uint8_t lazy_matching;         /* must be 0 in this release */
+    uint8_t lazy_matching;         /* compressor.c:576-619; about half the default mode's speed */
     uint8_t reserved[2];
 } TampAmdConf;
 
 /* Where the data pointers of a batch call live. */
 enum {
-    TAMP_AMD_MEM_HOST = 0,   /* host pointers: the library stages H2D / D2H itself */
+    TAMP_AMD_MEM_HOST = 0,   /* host pointers: the library stages H2D / D2H itself, in overlapping chunks on its
+                                own streams; pinned memory (tamp_amd_host_alloc) lets both copy directions run
+                                asynchronously at link speed, pageable memory works at the runtime's staging speed */
     TAMP_AMD_MEM_DEVICE = 1, /* device pointers on `device`: zero-copy, kernels only */
 };
+
+/* Page-locked host memory for TAMP_AMD_MEM_HOST calls, for callers that do not link the HIP runtime themselves
+ * (cgo / JNI / ctypes).  Not in the reference: its buffers never leave the CPU.  NULL when the allocation fails. */
+void *tamp_amd_host_alloc(size_t bytes);
+void tamp_amd_host_free(void *p);
 
 /* ---- host helpers (no device needed) -------------------------------------------------------- */
 
@@ -109,7 +116,8 @@ const char *tamp_amd_last_error(void);
  *   device                                      HIP device ordinal
  *   stream                                      hipStream_t (as void*) to enqueue on, or NULL for the default
  *                                               stream.  With device memory the call is asynchronous on `stream`;
- *                                               with host memory it synchronises before returning.
+ *                                               with host memory the call is synchronous and runs on the
+ *                                               library's own streams (`stream` is not used).
  * Returns TAMP_OK when the batch was launched (per-stream results are in status[]), or a negative
  * library-level code.
  */

@@ -34,6 +34,8 @@ SYMBOLS = (
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
+    "tamp_amd_host_alloc",
+    "tamp_amd_host_free",
     # include/tamp_compat.h: the reference's own symbol names
     "tamp_compressor_init",
     "tamp_compressor_compress_and_flush_cb",
@@ -118,6 +120,10 @@ def load() -> C.CDLL:
     lib.tamp_amd_set_timing.argtypes = [i32]
     lib.tamp_amd_set_timing.restype = None
     lib.tamp_amd_last_kernel_ms.restype = C.c_float
+    lib.tamp_amd_host_alloc.argtypes = [sz]
+    lib.tamp_amd_host_alloc.restype = vp
+    lib.tamp_amd_host_free.argtypes = [vp]
+    lib.tamp_amd_host_free.restype = None
     _lib = lib
     return lib
 

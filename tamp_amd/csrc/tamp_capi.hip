@@ -10,8 +10,12 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include <cstring>
 
@@ -41,6 +45,26 @@ struct DeviceCtx {
         uint32_t* scan = nullptr;  // header pre-pass results (largest window / longest stream / window bytes)
     };
     std::map<hipStream_t, Slab> slabs;
+    // host-memory batch calls (TAMP_AMD_MEM_HOST): kept staging buffers and the library's own streams, so that a
+    // call costs no hipMalloc and a large batch runs as overlapping chunks (copy in / kernel / copy out)
+    struct HostPipe {
+        static constexpr int kDepth = 3;
+        std::mutex mu;  // one host-memory batch call per device at a time
+        hipStream_t s[kDepth] = {nullptr, nullptr, nullptr};
+        struct Grow {
+            void* p = nullptr;
+            size_t bytes = 0;
+            hipError_t need(size_t n) {
+                if (n <= bytes) return hipSuccess;
+                if (p) (void)hipFree(p);
+                p = nullptr, bytes = 0;
+                n += n / 4 + 4096;
+                hipError_t e = hipMalloc(&p, n);
+                if (e == hipSuccess) bytes = n;
+                return e;
+            }
+        } in[kDepth], out[kDepth], meta[kDepth], dict;
+    } pipe;
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -397,6 +421,211 @@ bool conf_valid(const TampAmdConf* c) {
     return c && c->window >= 8 && c->window <= 15 && c->literal >= 5 && c->literal <= 8;  // compressor.c:208-209
 }
 
+// ---------------------------------------------------------------------------------------------
+// Host-memory batches.  The caller's arrays live in host memory (pageable or pinned); the batch is cut into chunks of
+// consecutive streams and each chunk goes copy-in -> kernel -> copy-out on one of three library streams, so the PCIe
+// transfers of neighbouring chunks (both directions) overlap the kernels.  A feeder thread issues copy-in + launch,
+// the calling thread issues copy-out: with pageable memory hipMemcpyAsync blocks its caller, and two issuers keep
+// both directions busy anyway.  Device staging is kept between calls.
+// ---------------------------------------------------------------------------------------------
+struct HostBatch {
+    const uint8_t* in;
+    const uint64_t* in_off;
+    const uint32_t* in_len;
+    uint8_t* out;
+    const uint64_t* out_off;
+    const uint32_t* out_cap;
+    uint32_t* out_len;
+    int8_t* status;
+    uint32_t* in_consumed;  // decompress only, may be null
+    size_t n;
+};
+
+struct HostChunk {
+    size_t i0, i1;
+    uint64_t in_lo, in_hi, out_lo, out_hi;
+};
+
+// Consecutive streams: a chunk closes once it holds `min_streams` streams and `min_bytes` of data (the larger of its
+// input and output extents), or earlier at `max_bytes`.  Needs both offset tables ascending and disjoint, the layout
+// every packed batch has; otherwise one chunk covers the whole batch.
+void plan_host_chunks(const HostBatch& b, size_t min_streams, uint64_t min_bytes, uint64_t max_bytes,
+                      std::vector<HostChunk>& chunks) {
+    bool ordered = true;
+    uint64_t in_end = 0, out_end = 0, in_max = 0, out_max = 0, in_min = ~0ull, out_min = ~0ull;
+    for (size_t i = 0; i < b.n; i++) {
+        ordered = ordered && b.in_off[i] >= in_end && b.out_off[i] >= out_end;
+        in_end = b.in_off[i] + b.in_len[i], out_end = b.out_off[i] + b.out_cap[i];
+        in_max = std::max(in_max, in_end), out_max = std::max(out_max, out_end);
+        in_min = std::min(in_min, b.in_off[i]), out_min = std::min(out_min, b.out_off[i]);
+    }
+    if (!ordered) {
+        chunks.push_back({0, b.n, in_min, in_max, out_min, out_max});
+        return;
+    }
+    size_t i0 = 0;
+    while (i0 < b.n) {
+        size_t i1 = i0 + 1;
+        for (; i1 < b.n; i1++) {
+            const uint64_t have = std::max(b.in_off[i1 - 1] + b.in_len[i1 - 1] - b.in_off[i0],
+                                           b.out_off[i1 - 1] + b.out_cap[i1 - 1] - b.out_off[i0]);
+            const uint64_t with = std::max(b.in_off[i1] + b.in_len[i1] - b.in_off[i0],
+                                           b.out_off[i1] + b.out_cap[i1] - b.out_off[i0]);
+            if ((i1 - i0 >= min_streams && have >= min_bytes) || with > max_bytes) break;
+        }
+        chunks.push_back({i0, i1, b.in_off[i0], b.in_off[i1 - 1] + b.in_len[i1 - 1], b.out_off[i0],
+                          b.out_off[i1 - 1] + b.out_cap[i1 - 1]});
+        i0 = i1;
+    }
+    // a short last chunk is a badly filled launch: give it to its neighbour
+    if (chunks.size() >= 2 && chunks.back().i1 - chunks.back().i0 < min_streams / 2) {
+        const HostChunk last = chunks.back();
+        chunks.pop_back();
+        chunks.back().i1 = last.i1, chunks.back().in_hi = last.in_hi, chunks.back().out_hi = last.out_hi;
+    }
+}
+
+struct HostSlot {  // device views of one chunk: offsets stay absolute, the data pointers are shifted instead
+    const uint8_t* in;
+    uint8_t* out;
+    const uint64_t *in_off, *out_off;
+    const uint32_t *in_len, *out_cap;
+    uint32_t *out_len, *in_consumed;
+    int8_t* status;
+};
+using HostLaunch = std::function<int(const HostSlot&, size_t count, const uint8_t* d_dict, hipStream_t)>;
+
+int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::vector<HostChunk>& chunks,
+                   const uint8_t* dictionary, size_t dictionary_len, const HostLaunch& launch) {
+    using Pipe = DeviceCtx::HostPipe;
+    Pipe& P = ctx->pipe;
+    std::lock_guard<std::mutex> call_lock(P.mu);
+    const uint8_t* d_dict = nullptr;
+    if (dictionary && dictionary_len) {
+        HIP_OK(P.dict.need(kSeedTable));
+        HIP_OK(hipMemcpy(P.dict.p, dictionary, std::min(dictionary_len, kSeedTable), hipMemcpyHostToDevice));
+        d_dict = static_cast<const uint8_t*>(P.dict.p);
+    }
+    size_t max_in = 0, max_out = 0, max_cnt = 0;
+    for (const HostChunk& ch : chunks) {
+        max_in = std::max<size_t>(max_in, ch.in_hi - ch.in_lo);
+        max_out = std::max<size_t>(max_out, ch.out_hi - ch.out_lo);
+        max_cnt = std::max(max_cnt, ch.i1 - ch.i0);
+    }
+    const int depth = (int)std::min<size_t>(Pipe::kDepth, chunks.size());
+    const size_t meta_bytes = max_cnt * (8 + 8 + 4 + 4 + 4 + 4 + 1) + 64;
+    for (int j = 0; j < depth; j++) {
+        if (!P.s[j]) HIP_OK(hipStreamCreateWithFlags(&P.s[j], hipStreamNonBlocking));
+        HIP_OK(P.in[j].need(max_in + 64));  // the kernels' vector loads may run past the last byte
+        HIP_OK(P.out[j].need(max_out + 1));
+        HIP_OK(P.meta[j].need(meta_bytes));
+    }
+    auto slot_of = [&](int j, const HostChunk& ch) {
+        HostSlot s;
+        uint8_t* m = static_cast<uint8_t*>(P.meta[j].p);
+        s.in_off = reinterpret_cast<uint64_t*>(m), m += max_cnt * 8;
+        s.out_off = reinterpret_cast<uint64_t*>(m), m += max_cnt * 8;
+        s.in_len = reinterpret_cast<uint32_t*>(m), m += max_cnt * 4;
+        s.out_cap = reinterpret_cast<uint32_t*>(m), m += max_cnt * 4;
+        s.out_len = reinterpret_cast<uint32_t*>(m), m += max_cnt * 4;
+        s.in_consumed = reinterpret_cast<uint32_t*>(m), m += max_cnt * 4;
+        s.status = reinterpret_cast<int8_t*>(m);
+        s.in = static_cast<const uint8_t*>(P.in[j].p) - ch.in_lo;
+        s.out = static_cast<uint8_t*>(P.out[j].p) - ch.out_lo;
+        return s;
+    };
+    auto feed = [&](size_t k) -> int {  // copy-in + launch of chunk k
+        const HostChunk& ch = chunks[k];
+        const int j = (int)(k % Pipe::kDepth);
+        const HostSlot s = slot_of(j, ch);
+        const size_t cnt = ch.i1 - ch.i0;
+        hipStream_t st = P.s[j];
+        if (ch.in_hi > ch.in_lo)
+            HIP_OK(hipMemcpyAsync(P.in[j].p, b.in + ch.in_lo, ch.in_hi - ch.in_lo, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(const_cast<uint64_t*>(s.in_off), b.in_off + ch.i0, cnt * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(const_cast<uint64_t*>(s.out_off), b.out_off + ch.i0, cnt * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(const_cast<uint32_t*>(s.in_len), b.in_len + ch.i0, cnt * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(const_cast<uint32_t*>(s.out_cap), b.out_cap + ch.i0, cnt * 4, hipMemcpyHostToDevice, st));
+        return launch(s, cnt, d_dict, st);
+    };
+    auto drain = [&](size_t k) -> int {  // copy-out of chunk k, complete on return
+        const HostChunk& ch = chunks[k];
+        const int j = (int)(k % Pipe::kDepth);
+        const HostSlot s = slot_of(j, ch);
+        const size_t cnt = ch.i1 - ch.i0;
+        hipStream_t st = P.s[j];
+        if (ch.out_hi > ch.out_lo)
+            HIP_OK(hipMemcpyAsync(b.out + ch.out_lo, P.out[j].p, ch.out_hi - ch.out_lo, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(b.out_len + ch.i0, s.out_len, cnt * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(b.status + ch.i0, s.status, cnt, hipMemcpyDeviceToHost, st));
+        if (b.in_consumed) HIP_OK(hipMemcpyAsync(b.in_consumed + ch.i0, s.in_consumed, cnt * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        return TAMP_OK;
+    };
+    if (chunks.size() == 1) {
+        int rc = feed(0);
+        return rc != TAMP_OK ? rc : drain(0);
+    }
+    std::mutex m;
+    std::condition_variable cv;
+    size_t fed = 0, drained = 0;
+    int feed_rc = TAMP_OK;
+    bool stop = false;
+    std::string feed_msg;
+    std::thread feeder([&] {
+        int rc = hipSetDevice(device) == hipSuccess ? TAMP_OK : TAMP_AMD_NO_DEVICE;
+        for (size_t k = 0; k < chunks.size() && rc == TAMP_OK; k++) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || k < drained + Pipe::kDepth; });  // slot k % kDepth is free again
+                if (stop) return;
+            }
+            rc = feed(k);
+            std::lock_guard<std::mutex> lk(m);
+            if (rc == TAMP_OK) fed = k + 1;
+            else feed_rc = rc, feed_msg = t_last_error;
+            cv.notify_all();
+        }
+        if (rc != TAMP_OK) {
+            std::lock_guard<std::mutex> lk(m);
+            if (feed_rc == TAMP_OK) feed_rc = rc;
+            cv.notify_all();
+        }
+    });
+    int rc = TAMP_OK;
+    for (size_t k = 0; k < chunks.size(); k++) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return fed > k || feed_rc != TAMP_OK; });
+            if (fed <= k) {
+                rc = feed_rc;
+                snprintf(t_last_error, sizeof t_last_error, "%s", feed_msg.c_str());
+                break;
+            }
+        }
+        rc = drain(k);
+        if (rc != TAMP_OK) break;
+        std::lock_guard<std::mutex> lk(m);
+        drained = k + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+        cv.notify_all();
+    }
+    feeder.join();
+    if (rc != TAMP_OK)
+        for (int j = 0; j < depth; j++) (void)hipStreamSynchronize(P.s[j]);  // nothing of this call left in flight
+    return rc;
+}
+
+size_t env_or(const char* name, size_t dflt) {  // tuning knobs of the host-memory path
+    const char* e = getenv(name);
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (size_t)v : dflt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,6 +683,16 @@ int tamp_amd_prof_read(unsigned long long* out6) {
 }
 #endif
 
+void* tamp_amd_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void tamp_amd_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
 
 float tamp_amd_last_kernel_ms(void) {
@@ -494,41 +733,23 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         return TAMP_OK;
     }
     if (n_streams == 0) return TAMP_OK;
-    uint64_t in_end = 0, out_end = 0;
-    uint32_t maxlen = 0;
-    for (size_t i = 0; i < n_streams; i++) {
-        if (in_off[i] + in_len[i] > in_end) in_end = in_off[i] + in_len[i];
-        if (out_off[i] + out_cap[i] > out_end) out_end = out_off[i] + out_cap[i];
-        if (in_len[i] > maxlen) maxlen = in_len[i];
+    if (!max_in_len) {
+        uint32_t maxlen = 0;
+        for (size_t i = 0; i < n_streams; i++) maxlen = std::max(maxlen, in_len[i]);
+        max_in_len = maxlen ? maxlen : 16;
     }
-    if (!max_in_len) max_in_len = maxlen ? maxlen : 16;
-    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_dict;
-    HIP_OK(d_in.alloc(in_end + 64));
-    HIP_OK(d_out.alloc(out_end));
-    HIP_OK(d_io.alloc(n_streams * 8));
-    HIP_OK(d_il.alloc(n_streams * 4));
-    HIP_OK(d_oo.alloc(n_streams * 8));
-    HIP_OK(d_oc.alloc(n_streams * 4));
-    HIP_OK(d_ol.alloc(n_streams * 4));
-    HIP_OK(d_st.alloc(n_streams));
-    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_streams * 8, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_streams * 4, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_streams * 8, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_streams * 4, hipMemcpyHostToDevice, st));
-    if (conf->use_custom_dictionary) {
-        HIP_OK(d_dict.alloc((size_t)1 << conf->window));
-        HIP_OK(hipMemcpyAsync(d_dict.p, dictionary, (size_t)1 << conf->window, hipMemcpyHostToDevice, st));
-    }
-    rc = launch_compress(ctx, conf, d_dict.as<uint8_t>(), d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(),
-                         d_out.as<uint8_t>(), d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(),
-                         d_st.as<int8_t>(), n_streams, max_in_len, st);
-    if (rc != TAMP_OK) return rc;
-    if (out_end) HIP_OK(hipMemcpyAsync(out, d_out.p, out_end, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_streams * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(status, d_st.p, n_streams, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    return TAMP_OK;
+    const HostBatch b = {in, in_off, in_len, out, out_off, out_cap, out_len, status, nullptr, n_streams};
+    std::vector<HostChunk> chunks;
+    // a chunk fills the device three times over (256 CUs x 6 workgroups = 1,536 streams at once); measured best for
+    // 4 KiB streams (tools/host_path_bench.py), and at least 16 MiB so that short messages do not drown in call overhead
+    plan_host_chunks(b, env_or("TAMP_AMD_HOST_CHUNK_STREAMS", (size_t)ctx->cu_count * 18),
+                     (uint64_t)env_or("TAMP_AMD_HOST_CHUNK_MB", 16) << 20, 1ull << 30, chunks);
+    return run_host_batch(ctx, device, b, chunks, conf->use_custom_dictionary ? dictionary : nullptr,
+                          (size_t)1 << conf->window,
+                          [&](const HostSlot& s, size_t count, const uint8_t* d_dict, hipStream_t cs) {
+        return launch_compress(ctx, conf, d_dict, s.in, s.in_off, s.in_len, s.out, s.out_off, s.out_cap, s.out_len,
+                               s.status, count, max_in_len, cs);
+    });
 }
 
 int tamp_batch_decompress(const uint8_t* dictionary, size_t dictionary_len, uint8_t max_window_bits, const uint8_t* in,
@@ -549,43 +770,19 @@ int tamp_batch_decompress(const uint8_t* dictionary, size_t dictionary_len, uint
                                  out_cap, out_len, status, in_consumed, n_streams, st);
 
     if (n_streams == 0) return TAMP_OK;
-    uint64_t in_end = 0, out_end = 0;
-    for (size_t i = 0; i < n_streams; i++) {
-        if (in_off[i] + in_len[i] > in_end) in_end = in_off[i] + in_len[i];
-        if (out_off[i] + out_cap[i] > out_end) out_end = out_off[i] + out_cap[i];
-    }
-    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_ic, d_dict;
-    HIP_OK(d_in.alloc(in_end + 64));
-    HIP_OK(d_out.alloc(out_end));
-    HIP_OK(d_io.alloc(n_streams * 8));
-    HIP_OK(d_il.alloc(n_streams * 4));
-    HIP_OK(d_oo.alloc(n_streams * 8));
-    HIP_OK(d_oc.alloc(n_streams * 4));
-    HIP_OK(d_ol.alloc(n_streams * 4));
-    HIP_OK(d_ic.alloc(n_streams * 4));
-    HIP_OK(d_st.alloc(n_streams));
-    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_streams * 8, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_streams * 4, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_streams * 8, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_streams * 4, hipMemcpyHostToDevice, st));
-    if (dictionary_len) {
-        const size_t use = dictionary_len < kSeedTable ? dictionary_len : kSeedTable;
-        HIP_OK(d_dict.alloc(use));
-        HIP_OK(hipMemcpyAsync(d_dict.p, dictionary, use, hipMemcpyHostToDevice, st));
-        dictionary_len = use;
-    }
-    rc = launch_decompress(ctx, dictionary_len ? d_dict.as<uint8_t>() : nullptr, dictionary_len, max_window_bits,
-                           d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(), d_out.as<uint8_t>(),
-                           d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(), d_st.as<int8_t>(),
-                           d_ic.as<uint32_t>(), n_streams, st);
-    if (rc != TAMP_OK) return rc;
-    if (out_end) HIP_OK(hipMemcpyAsync(out, d_out.p, out_end, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_streams * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(status, d_st.p, n_streams, hipMemcpyDeviceToHost, st));
-    if (in_consumed) HIP_OK(hipMemcpyAsync(in_consumed, d_ic.p, n_streams * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    return TAMP_OK;
+    dictionary_len = std::min(dictionary_len, kSeedTable);
+    const HostBatch b = {in, in_off, in_len, out, out_off, out_cap, out_len, status, in_consumed, n_streams};
+    std::vector<HostChunk> chunks;
+    // the lane-per-stream decoders want tens of thousands of streams per launch (launch_decompress)
+    plan_host_chunks(b, env_or("TAMP_AMD_HOST_CHUNK_STREAMS", (size_t)ctx->cu_count * 128),
+                     (uint64_t)env_or("TAMP_AMD_HOST_CHUNK_MB", 32) << 20, 1ull << 30, chunks);
+    uint32_t* no_consumed = nullptr;
+    return run_host_batch(ctx, device, b, chunks, dictionary, dictionary_len,
+                          [&](const HostSlot& s, size_t count, const uint8_t* d_dict, hipStream_t cs) {
+        return launch_decompress(ctx, d_dict, d_dict ? dictionary_len : 0, max_window_bits, s.in, s.in_off, s.in_len, s.out,
+                                 s.out_off, s.out_cap, s.out_len, s.status, in_consumed ? s.in_consumed : no_consumed,
+                                 count, cs);
+    });
 }
 
 tamp_res tamp_amd_compress(const TampAmdConf* conf, const unsigned char* dictionary, unsigned char* output,

@@ -607,3 +607,98 @@ def test_concurrent_streams_do_not_share_decoder_scratch(ta, monkeypatch):
         assert bool((back.out_len == L).all().item())
         got = back.out[: n * (L + 8)].view(n, L + 8)[:, :L].reshape(-1)
         assert torch.equal(got, data)
+
+
+def test_host_memory_batches_run_as_overlapping_chunks(ta, oracle, monkeypatch):
+    """Host-memory calls (TAMP_AMD_MEM_HOST) are cut into chunks of consecutive streams that overlap on the library's
+    own HIP streams: results must not depend on where the cuts fall -- ragged and empty streams, per-stream error
+    codes, consumed counts, pinned and pageable buffers, an unordered offset table (one chunk), and two host threads
+    calling at once."""
+    import ctypes as C
+    import threading
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+    rng = random.Random(99)
+    datas = []
+    for i in range(1500):
+        n = rng.choice([0, 1, 17, 300, 2048, 4096, rng.randrange(1, 6000)])
+        x = _rand_inputs(rng, wl, n)
+        datas.append(x)
+    datas[7] = b"\xff" * 40 + datas[7]  # fine with literal=8; gives EXCESS_BITS below with literal=7
+    want8 = [oracle.compress(x, window=10, literal=8) for x in datas]
+    want7 = [oracle.compress(x, window=9, literal=7) for x in datas[:200]]
+
+    monkeypatch.setenv("TAMP_AMD_HOST_CHUNK_MB", "1")
+    for streams in ("16", "200", "100000"):
+        monkeypatch.setenv("TAMP_AMD_HOST_CHUNK_STREAMS", streams)
+        res = ta.compress_batch(datas, window=10, literal=8)
+        for j, (st, blob) in enumerate(want8):
+            assert int(res.status[j]) == st and res.stream(j) == blob, (streams, j)
+        res7 = ta.compress_batch(datas[:200], window=9, literal=7)
+        for j, (st, blob) in enumerate(want7):
+            assert int(res7.status[j]) == st and res7.stream(j) == blob, (streams, j)
+        assert any(st == _lib.EXCESS_BITS for st, _ in want7)
+        # decode with exact, short and generous capacities, and a truncated stream
+        dec_in, caps = [], []
+        for x, (st, blob) in zip(datas, want8):
+            dec_in.append(blob), caps.append(len(x) + rng.randrange(0, 9))
+            if len(x) > 4:
+                dec_in.append(blob), caps.append(len(x) - rng.randrange(1, 4))
+                dec_in.append(blob[: len(blob) // 2]), caps.append(len(x))
+        back = ta.decompress_batch(dec_in, out_cap=np.array(caps, dtype=np.uint32))
+        for j, (blob, cap) in enumerate(zip(dec_in, caps)):
+            want = oracle.decompress(blob, cap=cap)
+            assert (int(back.status[j]), back.stream(j), int(back.in_consumed[j])) == want, (streams, j)
+
+    # pinned buffers (tamp_amd_host_alloc) and an offset table that is not ascending: one chunk, same bytes
+    monkeypatch.setenv("TAMP_AMD_HOST_CHUNK_STREAMS", "64")
+    flat, in_off, in_len = ta.pack_streams(datas)
+    n = len(datas)
+    cap = np.array([ta.compress_bound(len(x), 8, False) for x in datas], dtype=np.uint32)
+    out_off = np.cumsum(cap, dtype=np.uint64) - cap
+
+    def pinned(arr):
+        p = lib.tamp_amd_host_alloc(max(arr.nbytes, 1))
+        assert p
+        view = np.frombuffer((C.c_ubyte * max(arr.nbytes, 1)).from_address(p), dtype=arr.dtype, count=arr.size)
+        view[:] = arr
+        return p, view
+
+    held = [pinned(a) for a in (flat, in_off.astype(np.uint64), in_len.astype(np.uint32), out_off, cap)]
+    p_out, v_out = pinned(np.zeros(int(cap.sum()) + 1, np.uint8))
+    p_len, v_len = pinned(np.zeros(n, np.uint32))
+    p_st, v_st = pinned(np.zeros(n, np.int8))
+    conf = _lib.TampAmdConf(window=10, literal=8, extended=1)
+    rc = lib.tamp_batch_compress(C.byref(conf), None, held[0][0], held[1][0], held[2][0], p_out, held[3][0], held[4][0],
+                                 p_len, p_st, n, 0, _lib.MEM_HOST, 0, None)
+    assert rc == 0
+    for j, (st, blob) in enumerate(want8):
+        assert int(v_st[j]) == st and bytes(v_out[int(out_off[j]) : int(out_off[j]) + int(v_len[j])]) == blob, j
+    for p, _ in held + [(p_out, 0), (p_len, 0), (p_st, 0)]:
+        lib.tamp_amd_host_free(p)
+
+    perm = np.arange(n)[::-1].copy()  # same slab, streams listed last-first
+    res = ta.compress_batch(flat, in_off[perm], in_len[perm], window=10)
+    for k, j in enumerate(perm):
+        assert int(res.status[k]) == want8[j][0] and res.stream(k) == want8[j][1], (k, j)
+
+    errs = []
+
+    def worker(lo, hi):
+        try:
+            for _ in range(3):
+                r = ta.compress_batch(datas[lo:hi], window=10)
+                for j in range(lo, hi):
+                    assert r.stream(j - lo) == want8[j][1]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(0, 700)), threading.Thread(target=worker, args=(700, 1500))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
