@@ -220,6 +220,46 @@ class Oracle(_Base):
                                        max_window_bits, _p(out), cap, C.byref(n), C.byref(c))
         return r, out[: n.value].tobytes(), c.value
 
+    def decode_script(self, data, script, *, conf=None, window_bits=15, dictionary=None):
+        """One resumable decoder object fed call by call.  ``script`` = [(take, cap), ...]: each call sees the next
+        ``take`` unconsumed bytes of ``data`` and ``cap`` bytes of output room; what it does not consume is offered
+        again.  ``conf`` = None (header from the stream) or (window, literal, custom, extended, dictionary_reset) with
+        ``data`` starting after the header.  -> (init status, [(status, bytes, consumed), ...])"""
+        L = self.lib
+
+        class _Dec(C.Structure):
+            _fields_ = [("bit_buffer", C.c_uint32), ("window_pos", C.c_uint16), ("bit_buffer_pos", C.c_uint8),
+                        ("token_state", C.c_uint8), ("pending_window_offset", C.c_uint16),
+                        ("pending_match_size", C.c_uint16), ("conf", C.c_uint8), ("skip_bytes", C.c_uint8),
+                        ("flags", C.c_uint8), ("window_bits_max", C.c_uint8)]
+
+        L.oracle_decoder_init.restype = C.c_int
+        L.oracle_decoder_init.argtypes = [C.POINTER(_Dec), C.c_void_p, C.c_void_p, C.c_uint8]
+        L.oracle_decoder_call.restype = C.c_int
+        L.oracle_decoder_call.argtypes = [C.POINTER(_Dec), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        d = _Dec()
+        win = np.zeros(1 << 15, dtype=np.uint8)
+        if dictionary is not None:
+            dd = _u8(dictionary)[: 1 << 15]
+            win[: len(dd)] = dd
+        oc = _OracleConf(conf[0], conf[1], int(conf[2]), int(conf[3]), int(conf[4]), 0) if conf is not None else None
+        r0 = L.oracle_decoder_init(C.byref(d), _p(win), C.byref(oc) if oc is not None else None, window_bits)
+        calls = []
+        if r0 != OK:
+            return r0, calls
+        a = _u8(data)
+        pos = 0
+        for take, cap in script:
+            chunk = np.ascontiguousarray(a[pos : pos + take])
+            out = np.zeros(cap + 1, dtype=np.uint8)
+            w, k = C.c_size_t(0), C.c_size_t(0)
+            r = L.oracle_decoder_call(C.byref(d), _p(win), _p(chunk) if len(chunk) else None, len(chunk), _p(out), cap,
+                                      C.byref(w), C.byref(k))
+            calls.append((r, out[: w.value].tobytes(), k.value))
+            pos += k.value
+        return r0, calls
+
 
 class Ref(_Base):
     prefix = "ref"
@@ -315,3 +355,35 @@ class Ref(_Base):
         r = self.lib.ref_decompress(_p(a), len(a), _p(d) if d is not None else None, len(d) if d is not None else 0,
                                     max_window_bits, _p(out), cap, C.byref(n), C.byref(c))
         return r, out[: n.value].tobytes(), c.value
+
+    def decode_script(self, data, script, *, conf=None, window_bits=15, dictionary=None):
+        """``Oracle.decode_script`` on a real reference TampDecompressor object."""
+        L = self.lib
+        L.ref_decoder_new.restype = C.c_void_p
+        L.ref_decoder_new.argtypes = [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.ref_decoder_call.restype = C.c_int
+        L.ref_decoder_call.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ref_decoder_free.argtypes = [C.c_void_p]
+        dd = _u8(dictionary) if dictionary is not None else None
+        r0 = C.c_int(0)
+        cf = conf if conf is not None else (-1, 0, 0, 0, 0)
+        h = L.ref_decoder_new(int(cf[0]), int(cf[1]), int(cf[2]), int(cf[3]), int(cf[4]), window_bits,
+                              _p(dd) if dd is not None else None, len(dd) if dd is not None else 0, C.byref(r0))
+        calls = []
+        try:
+            if r0.value != OK:
+                return r0.value, calls
+            a = _u8(data)
+            pos = 0
+            for take, cap in script:
+                chunk = np.ascontiguousarray(a[pos : pos + take])
+                out = np.zeros(cap + 1, dtype=np.uint8)
+                w, k = C.c_size_t(0), C.c_size_t(0)
+                r = L.ref_decoder_call(h, _p(chunk) if len(chunk) else None, len(chunk), _p(out), cap, C.byref(w),
+                                       C.byref(k))
+                calls.append((r, out[: w.value].tobytes(), k.value))
+                pos += k.value
+            return r0.value, calls
+        finally:
+            L.ref_decoder_free(h)

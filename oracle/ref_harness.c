@@ -114,6 +114,39 @@ int ref_stream_reset_dictionary(void *h, unsigned char *out, size_t cap, size_t 
 
 void ref_stream_free(void *h) { free(h); }
 
+/* ---- resumable decoder object, one tamp_decompressor_decompress call at a time ---- */
+
+typedef struct {
+    TampDecompressor d;
+    unsigned char window[1 << 15];
+} RefDecoder;
+
+/* window < 0: conf = NULL (the header comes from the stream); dict, when given, pre-fills the window buffer */
+void *ref_decoder_new(int window, int literal, int custom, int extended, int dictionary_reset, int window_bits,
+                      const unsigned char *dict, size_t dict_len, int *res_out) {
+    RefDecoder *s = (RefDecoder *)calloc(1, sizeof *s);
+    if (dict) memcpy(s->window, dict, dict_len < sizeof s->window ? dict_len : sizeof s->window);
+    TampConf conf;
+    memset(&conf, 0, sizeof conf);
+    if (window >= 0) {
+        conf.window = (uint16_t)window;
+        conf.literal = (uint16_t)literal;
+        conf.use_custom_dictionary = custom != 0;
+        conf.extended = extended != 0;
+        conf.dictionary_reset = dictionary_reset != 0;
+    }
+    int res = tamp_decompressor_init(&s->d, window >= 0 ? &conf : NULL, s->window, (uint8_t)window_bits);
+    if (res_out) *res_out = res;
+    return s;
+}
+
+int ref_decoder_call(void *h, const unsigned char *in, size_t n, unsigned char *out, size_t cap, size_t *written,
+                     size_t *consumed) {
+    return tamp_decompressor_decompress(&((RefDecoder *)h)->d, out, cap, written, in, n, consumed);
+}
+
+void ref_decoder_free(void *h) { free(h); }
+
 /* ---- multi-threaded batch drivers for the cpu_baseline leg of bench.py ---- */
 
 typedef struct {

@@ -672,3 +672,249 @@ finish:
 #undef REFILL
 #undef TAKE
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Resumable decoder: the reference's TampDecompressor object as a value (decompressor.h:13-57) plus the
+ * caller's window buffer, advanced by one tamp_decompressor_decompress call at a time with whatever input and
+ * output room that call has (decompressor.c:371-578).  Test infrastructure, like the rest of this file.
+ * --------------------------------------------------------------------------------------------- */
+enum { DS_CONFIGURED = 1, DS_HEADER_STASHED = 2, DS_LAST_WAS_FLUSH = 4 };
+enum { TS_NONE = 0, TS_RLE = 1, TS_EXT_FRESH = 2, TS_EXT_HAVE_SIZE = 3 }; /* decompressor.c:39-42 */
+
+static int decoder_configure(OracleDecoder *d, uint8_t *window, unsigned wbits, unsigned lbits, int custom, int extended,
+                             int dreset) {
+    /* tamp_decompressor_populate_from_conf, decompressor.c:304-329 */
+    if (wbits < 8 || wbits > 15 || lbits < 5 || lbits > 8 || wbits > d->window_bits_max) return ORACLE_INVALID_CONF;
+    if (!custom) oracle_initialize_dictionary(window, (size_t)1 << wbits, extended ? (uint8_t)lbits : 8);
+    d->conf = (uint8_t)(((wbits - 8) << 5) | ((lbits - 5) << 3) | (custom << 2) | (extended << 1) | dreset);
+    d->flags |= DS_CONFIGURED;
+    return ORACLE_OK;
+}
+
+int oracle_decoder_init(OracleDecoder *d, uint8_t *window, const OracleConf *conf, uint8_t window_bits_max) {
+    if (window_bits_max < 8 || window_bits_max > 15) return ORACLE_INVALID_CONF; /* decompressor.c:336 */
+    memset(d, 0, sizeof *d);
+    d->window_bits_max = window_bits_max;
+    if (!conf) return ORACLE_OK;
+    return decoder_configure(d, window, conf->window, conf->literal, conf->use_custom_dictionary, conf->extended,
+                             conf->dictionary_reset);
+}
+
+int oracle_decoder_call(OracleDecoder *d, uint8_t *win, const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                        size_t *written, size_t *consumed) {
+    size_t ip = 0, op = 0;
+    int res = ORACLE_INPUT_EXHAUSTED;
+#define DONE(code)     \
+    do {               \
+        res = (code);  \
+        goto finish;   \
+    } while (0)
+
+    if (!(d->flags & DS_CONFIGURED)) { /* decompressor.c:389-429 */
+        unsigned h0;
+        if (d->flags & DS_HEADER_STASHED) {
+            h0 = d->skip_bytes; /* the stash shares storage with skip_bytes */
+            if (n == 0) DONE(ORACLE_INPUT_EXHAUSTED);
+            if (in[0]) DONE(ORACLE_INVALID_CONF);
+            ip = 1;
+        } else {
+            if (n == 0) DONE(ORACLE_INPUT_EXHAUSTED);
+            h0 = in[0];
+            if ((h0 & 1) && n < 2) {
+                d->skip_bytes = (uint8_t)h0;
+                d->flags |= DS_HEADER_STASHED;
+                ip = 1;
+                DONE(ORACLE_INPUT_EXHAUSTED);
+            }
+            if ((h0 & 1) && in[1]) DONE(ORACLE_INVALID_CONF);
+            ip = 1 + (h0 & 1);
+        }
+        int rc = decoder_configure(d, win, ((h0 >> 5) & 7) + 8, ((h0 >> 3) & 3) + 5, (h0 >> 2) & 1, (h0 >> 1) & 1, h0 & 1);
+        if (rc != ORACLE_OK) DONE(rc);
+        d->skip_bytes = 0;
+        d->flags &= (uint8_t)~DS_HEADER_STASHED;
+    }
+    {
+        const unsigned wbits = ((d->conf >> 5) & 7) + 8, lbits = ((d->conf >> 3) & 3) + 5;
+        const int extended = (d->conf >> 1) & 1, dreset = d->conf & 1;
+        const uint32_t W = 1u << wbits, mask = W - 1;
+        const unsigned minp = (unsigned)oracle_min_pattern_size((uint8_t)wbits, (uint8_t)lbits);
+        uint32_t bb = d->bit_buffer;
+        unsigned nb = d->bit_buffer_pos;
+        uint32_t wp = d->window_pos;
+#define REFILL()                               \
+    while (ip < n && nb <= 24) {               \
+        nb += 8;                               \
+        bb |= (uint32_t)in[ip++] << (32 - nb); \
+    }
+#define SAVE() (d->bit_buffer = bb, d->bit_buffer_pos = (uint8_t)nb, d->window_pos = (uint16_t)wp)
+
+        while (ip < n || nb || d->token_state) { /* decompressor.c:431 */
+            if (op == cap) {
+                SAVE();
+                DONE(ORACLE_OUTPUT_FULL);
+            }
+            REFILL();
+
+            if (d->token_state) { /* decompressor.c:441-462, with decode_rle / decode_extended_match inline */
+            dispatch:;
+                const int rle = d->token_state == TS_RLE;
+                const unsigned trailing = rle ? 4u : 3u;
+                unsigned skip = d->skip_bytes, count, off = 0;
+                int starved = 0;
+                if (skip) {
+                    count = rle ? d->pending_window_offset : d->pending_match_size;
+                    off = d->pending_window_offset;
+                } else {
+                    if (d->token_state == TS_EXT_HAVE_SIZE) {
+                        count = d->pending_match_size;
+                    } else {
+                        unsigned used = 0;
+                        int hs = (nb >= 1 + trailing) ? read_symbol(bb, nb, &used) : -1;
+                        if (hs >= 0 && nb - used < trailing) hs = -1;
+                        if (hs < 0) {
+                            starved = 1;
+                            count = 0;
+                        } else {
+                            bb <<= used, nb -= used;
+                            count = ((unsigned)hs << trailing) + (bb >> (32 - trailing));
+                            bb <<= trailing, nb -= trailing;
+                            count += rle ? 2u : minp + 12u;
+                        }
+                    }
+                    if (!starved && !rle) {
+                        if (nb < wbits) { /* size known, offset not yet: decompressor.c:215-222 */
+                            d->token_state = TS_EXT_HAVE_SIZE;
+                            d->pending_match_size = (uint16_t)count;
+                            starved = 1;
+                        } else {
+                            off = bb >> (32 - wbits);
+                            bb <<= wbits, nb -= wbits;
+                        }
+                    }
+                }
+                if (starved) { /* decompressor.c:447-456 */
+                    const unsigned before = nb;
+                    REFILL();
+                    if (nb == before && ip == n) {
+                        SAVE();
+                        DONE(ORACLE_INPUT_EXHAUSTED);
+                    }
+                    continue;
+                }
+                if (!rle && (off >= W || off + count > W)) {
+                    SAVE();
+                    DONE(ORACLE_OOB);
+                }
+                const unsigned remaining = count - skip;
+                const size_t room = cap - op;
+                unsigned w;
+                if (remaining > room) { /* partial: remember where to pick up */
+                    w = (unsigned)room;
+                    d->skip_bytes = (uint8_t)(skip + w);
+                    d->token_state = rle ? TS_RLE : TS_EXT_HAVE_SIZE;
+                    d->pending_window_offset = (uint16_t)(rle ? count : off);
+                    if (!rle) d->pending_match_size = (uint16_t)count;
+                } else {
+                    w = remaining;
+                    d->skip_bytes = 0;
+                    d->token_state = TS_NONE;
+                }
+                if (rle) {
+                    memset(out + op, win[(wp - 1) & mask], w);
+                    if (skip == 0) { /* window: first piece only, at most 8 bytes, no wrap */
+                        const uint8_t c = win[(wp - 1) & mask];
+                        unsigned ww = umin(umin(count, RLE_WINDOW_MAX), W - wp);
+                        for (unsigned i = 0; i < ww; i++) win[wp++] = c;
+                        wp &= mask;
+                    }
+                } else {
+                    memcpy(out + op, win + off + skip, w);
+                    if (d->token_state == TS_NONE) window_copy(win, &wp, off, umin(count, W - wp), mask);
+                }
+                op += w;
+                if (d->token_state != TS_NONE) {
+                    SAVE();
+                    DONE(ORACLE_OUTPUT_FULL);
+                }
+                continue;
+            }
+
+            if (nb == 0) {
+                SAVE();
+                DONE(ORACLE_INPUT_EXHAUSTED);
+            }
+            if (bb >> 31) { /* literal */
+                d->flags &= (uint8_t)~DS_LAST_WAS_FLUSH;
+                if (nb < 1 + lbits) {
+                    SAVE();
+                    DONE(ORACLE_INPUT_EXHAUSTED);
+                }
+                const uint8_t c = (uint8_t)((bb << 1) >> (32 - lbits));
+                bb <<= 1 + lbits, nb -= 1 + lbits;
+                out[op++] = c;
+                win[wp] = c;
+                wp = (wp + 1) & mask;
+                continue;
+            }
+            uint32_t b2 = bb << 1;
+            unsigned n2 = nb - 1, used = 0;
+            const int sym = read_symbol(b2, n2, &used);
+            if (sym < 0) {
+                SAVE();
+                DONE(ORACLE_INPUT_EXHAUSTED);
+            }
+            b2 <<= used, n2 -= used;
+            if (sym == SYM_FLUSH) {
+                bb = b2 << (n2 & 7);
+                nb = n2 & ~7u;
+                if (dreset && (d->flags & DS_LAST_WAS_FLUSH)) {
+                    wp = 0;
+                    oracle_initialize_dictionary(win, W, extended ? (uint8_t)lbits : 8);
+                }
+                d->flags |= DS_LAST_WAS_FLUSH;
+                continue;
+            }
+            d->flags &= (uint8_t)~DS_LAST_WAS_FLUSH;
+            if (extended && sym >= SYM_RLE) { /* symbol committed, payload handled at the loop head */
+                bb = b2, nb = n2;
+                d->token_state = (uint8_t)(sym == SYM_RLE ? TS_RLE : TS_EXT_FRESH);
+                /* straight into the dispatch (decompressor.c:521-527): no refill in between, so a token that ends
+                 * the call (output full) leaves the input cursor where it was */
+                goto dispatch;
+            }
+            if (n2 < wbits) {
+                SAVE();
+                DONE(ORACLE_INPUT_EXHAUSTED);
+            }
+            const unsigned match_len = (unsigned)sym + minp;
+            const uint32_t off = b2 >> (32 - wbits);
+            if (off >= W || off + match_len > W) {
+                SAVE();
+                DONE(ORACLE_OOB);
+            }
+            const unsigned skip = d->skip_bytes;
+            unsigned w = match_len - skip;
+            const size_t room = cap - op;
+            if (w > room) { /* token stays in the bit buffer; the next call decodes it again and skips */
+                w = (unsigned)room;
+                d->skip_bytes = (uint8_t)(skip + w);
+            } else {
+                d->skip_bytes = 0;
+                bb = b2 << wbits;
+                nb = n2 - wbits;
+            }
+            memcpy(out + op, win + off + skip, w);
+            op += w;
+            if (d->skip_bytes == 0) window_copy(win, &wp, off, match_len, mask);
+        }
+        SAVE();
+    }
+finish:
+    if (written) *written = op;
+    if (consumed) *consumed = ip;
+    return res;
+#undef DONE
+#undef REFILL
+#undef SAVE
+}

@@ -91,6 +91,26 @@ int oracle_compress_segment(const OracleConf *conf, int emit_header, int append_
 int oracle_decompress(const uint8_t *in, size_t n, const uint8_t *dict, size_t dict_len, uint8_t max_window_bits,
                       uint8_t *out, size_t cap, size_t *out_len, size_t *in_consumed);
 
+/* Resumable decoder = the reference's TampDecompressor object by value (decompressor.h:13-57; 16 bytes of state next
+ * to the caller's window buffer).  oracle_decoder_init follows tamp_decompressor_init (decompressor.c:331-347; conf
+ * NULL = read the header from the stream), oracle_decoder_call one tamp_decompressor_decompress call
+ * (decompressor.c:371-578): any input size, any output room, OUTPUT_FULL / INPUT_EXHAUSTED and pick up later. */
+typedef struct OracleDecoder {
+    uint32_t bit_buffer;
+    uint16_t window_pos;
+    uint8_t bit_buffer_pos;
+    uint8_t token_state;
+    uint16_t pending_window_offset;
+    uint16_t pending_match_size;
+    uint8_t conf;       /* header byte 0 once configured */
+    uint8_t skip_bytes; /* before the header is complete: its stashed first byte */
+    uint8_t flags;      /* 1 configured, 2 header byte stashed, 4 last token was FLUSH */
+    uint8_t window_bits_max;
+} OracleDecoder;
+int oracle_decoder_init(OracleDecoder *d, uint8_t *window, const OracleConf *conf, uint8_t window_bits_max);
+int oracle_decoder_call(OracleDecoder *d, uint8_t *window, const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                        size_t *written, size_t *consumed);
+
 /* Per-token trace hook for debugging the HIP path (kind: 0 literal, 1 match, 2 rle, 3 ext). */
 typedef void (*oracle_token_cb)(void *user, int kind, size_t in_pos, unsigned len, unsigned index);
 void oracle_set_token_cb(oracle_token_cb cb, void *user);

@@ -13,6 +13,8 @@ Two kinds of fixture are written:
 * ``dictionaries.json`` -- tamp_initialize_dictionary for every (size, literal) pair.
 * ``streaming.json`` -- op scripts (write / flush / reset_dictionary / close) replayed on one reference
   compressor object, with the bytes it emitted.
+* ``decoder_resume.json`` -- call scripts (input chunk, output room) replayed on one reference decompressor
+  object, with each call's status / bytes / consumed count.
 * ``device_vectors.json`` -- the reference's malformed/valid decoder vectors
   (devices/vectors/*.bin, data files its own tests replay) with the status/output the reference
   decoder produces for them.
@@ -278,6 +280,90 @@ def streaming(ref: Ref):
     return recs
 
 
+def decoder_resume(ref: Ref):
+    """Call scripts on ONE reference decompressor object (decompressor.c:371-578): each call gets the next `take`
+    unconsumed bytes and `cap` bytes of output room -- the output-full / input-exhausted resume shapes of
+    tests/test_decompressor.py:99-144, ctests/test_decompressor.c:105-144 and tests/test_compressor_decompressor.py
+    (flush / reset streams) on this repo's synthetic inputs, plus seeded random scripts.  Recorded per call:
+    status, bytes written (base64), bytes consumed."""
+    import random
+
+    text = bytes(wl.synth_text(1, 3000, first_index=91)[0])
+    runs = bytes(wl.lcg_runs(1, 2500, first_index=9)[0])
+    zeros = bytes(700) + b"abcabcabcabc" * 30 + bytes(300)
+    W, F, R, CL = (lambda b: ("write", b)), (lambda t: ("flush", t)), ("reset",), ("close",)
+
+    def stream(plain, **kw):
+        st, blob = ref.stream_script([W(plain), CL], **kw)
+        assert st == 0
+        return blob
+
+    sources = {
+        "text_w10": (stream(text), {}),
+        "text_v1_w9": (stream(text, window=9, extended=False), {}),
+        "runs_w10": (stream(runs), {}),
+        "runs_w8": (stream(runs, window=8), {}),
+        "zeros_w10": (stream(zeros), {}),
+        "text_l7_w12": (stream(bytes(b & 127 for b in text), window=12, literal=7), {}),
+    }
+    st, blob = ref.stream_script([W(text[:500]), F(True), W(runs[:400]), R, W(zeros[:800]), F(True), F(True), W(text[500:900]), CL],
+                                 dictionary_reset=True)
+    assert st == 0
+    sources["flush_and_reset"] = (blob, {})
+    dic = (text[1000:1256] * 8)[:1024]
+    st, blob = ref.stream_script([W(text[:1500]), CL], dictionary=dic)
+    assert st == 0
+    sources["custom_dictionary"] = (blob, {"dictionary": dic})
+
+    fixed = [
+        ("one_byte_at_a_time", "text_w10", [(1, 4096)] * 1700),
+        ("output_one_byte", "runs_w10", [(4096, 1)] * 2600),
+        ("output_full_resume_small", "zeros_w10", [(4096, 7)] * 300),
+        ("output_full_resume_16", "text_v1_w9", [(4096, 16)] * 200),
+        ("both_tiny", "runs_w8", [(2, 3)] * 1500),
+        ("zero_room_calls", "text_w10", [(5, 0), (5, 10), (0, 10), (5, 0)] * 50),
+        ("whole_then_empty_calls", "flush_and_reset", [(1 << 20, 1 << 16), (0, 16), (0, 0)]),
+        ("flush_reset_small_calls", "flush_and_reset", [(3, 5)] * 1500),
+        ("custom_dictionary_chunks", "custom_dictionary", [(50, 64)] * 200),
+        ("literal7_chunks", "text_l7_w12", [(9, 33)] * 400),
+    ]
+    recs = []
+
+    def record(name, src, script, conf=None, window_bits=15, mutate=None):
+        blob, kw = sources[src]
+        data = blob
+        if mutate is not None:
+            b = bytearray(blob)
+            b[mutate[0] % len(b)] ^= 1 << mutate[1]
+            data = bytes(b)
+        if conf is not None:
+            data = data[1 + (data[0] & 1) :]
+        r0, calls = ref.decode_script(data, script, conf=conf, window_bits=window_bits, dictionary=kw.get("dictionary"))
+        # drop the tail of calls that neither consume nor produce (keeps the file small)
+        while len(calls) > 1 and calls[-1][1] == b"" and calls[-1][2] == 0 and calls[-2][1] == b"" and calls[-2][2] == 0:
+            calls.pop()
+        script = script[: len(calls)]
+        recs.append(dict(name=name, source=src, data=b64(data), conf=list(conf) if conf is not None else None,
+                         window_bits=window_bits, dictionary=b64(kw["dictionary"]) if "dictionary" in kw else None,
+                         script=[list(s) for s in script], init=r0,
+                         calls=[[r, b64(out), k] for r, out, k in calls]))
+
+    for name, src, script in fixed:
+        record(name, src, script)
+    record("conf_given_skip_header", "text_w10", [(7, 50)] * 400, conf=(10, 8, False, True, False))
+    record("window_bits_too_small", "text_l7_w12", [(10, 10)] * 3, window_bits=10)
+    record("stashed_header_byte", "flush_and_reset", [(1, 10), (0, 10), (1, 10), (100, 10)])
+    rng = random.Random(20260928)
+    names = sorted(sources)
+    for k in range(40):
+        src = rng.choice(names)
+        script = [(rng.choice([0, 1, 2, 3, 5, 9, 40, 1000]), rng.choice([0, 1, 2, 3, 7, 20, 64, 300])) for _ in range(rng.randrange(5, 400))]
+        script.append((1 << 20, 1 << 15))
+        mutate = (rng.randrange(1, 4000), rng.randrange(8)) if rng.random() < 0.3 else None
+        record(f"random_{k}", src, script, mutate=mutate, window_bits=rng.choice([15, 15, 12]))
+    return recs
+
+
 def main():
     ref = Ref()
     assert ref.sizes() == (2, 48, 24), ref.sizes()
@@ -287,6 +373,7 @@ def main():
         ("generated.json", generated(ref)),
         ("device_vectors.json", device_vectors(ref)),
         ("streaming.json", streaming(ref)),
+        ("decoder_resume.json", decoder_resume(ref)),
     ):
         with open(os.path.join(HERE, fname), "w") as f:
             json.dump(obj, f, indent=0, sort_keys=True)

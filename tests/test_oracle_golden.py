@@ -109,6 +109,27 @@ def test_streaming_scripts(oracle):
             assert dst == 2 and hashlib.sha256(back).hexdigest() == rec["plain_sha256"], rec["name"]
 
 
+def _resume_record(rec):
+    conf = tuple(rec["conf"]) if rec["conf"] is not None else None
+    dic = unb64(rec["dictionary"]) if rec["dictionary"] else None
+    script = [tuple(s) for s in rec["script"]]
+    want = [(r, unb64(out), k) for r, out, k in rec["calls"]]
+    return unb64(rec["data"]), script, conf, dic, want
+
+
+def test_decoder_resume_scripts(oracle):
+    """One decompressor object driven call by call with small inputs and small output room: status, bytes and
+    consumed count of every call as recorded from the reference (tests/golden/decoder_resume.json; shapes of
+    tests/test_decompressor.py:99-144, ctests/test_decompressor.c:105-144)."""
+    recs = load_golden("decoder_resume.json")
+    assert len(recs) >= 50
+    for rec in recs:
+        data, script, conf, dic, want = _resume_record(rec)
+        r0, calls = oracle.decode_script(data, script, conf=conf, window_bits=rec["window_bits"], dictionary=dic)
+        assert r0 == rec["init"], rec["name"]
+        assert calls == want, rec["name"]
+
+
 def test_invalid_conf(oracle):
     # compressor.c:208-209, tests/test_compressor.py:420-433
     assert oracle.compress(b"x", window=7)[0] == -3
