@@ -151,6 +151,44 @@ int tamp_batch_decompress(const uint8_t *dictionary, size_t dictionary_len, uint
                           const uint32_t *out_cap, uint32_t *out_len, int8_t *status, uint32_t *in_consumed,
                           size_t n_streams, int mem, int device, void *stream);
 
+/* ---- resumable decoding: decoder OBJECTS that survive between calls ------------------------------
+ *
+ * What TampDecompressor is in the reference (decompressor.h:13-57): 16 bytes of state next to a window buffer,
+ * advanced by tamp_decompressor_decompress (decompressor.h:93-128, decompressor.c:371-578) with whatever input and
+ * output room one call has -- TAMP_OUTPUT_FULL / TAMP_INPUT_EXHAUSTED and pick up later, mid-token if need be.
+ * Here the objects live in one array (host or device memory, like every other pointer of the call):
+ *   object i = states + i * state_stride:  TampAmdDecoderState (16 B), then its window of 1 << window_bits_max bytes
+ * state_stride >= tamp_amd_decoder_state_size(window_bits_max), a multiple of 16.  One call advances every object by
+ * one step: object i sees in[in_off[i] .. +in_len[i]) and out_cap[i] bytes of room, and status / out_len /
+ * in_consumed come back as from the reference's call.  Input that was not consumed must be offered again.
+ */
+typedef struct TampAmdDecoderState {
+    uint32_t bit_buffer;            /* bits pulled from the input and not yet decoded, left aligned */
+    uint16_t window_pos;
+    uint8_t bit_buffer_pos;         /* how many */
+    uint8_t token_state;            /* 0 none, 1 RLE, 2 extended match, 3 extended match with its size known */
+    uint16_t pending_window_offset; /* token cut short by a full output buffer: where it copies from (RLE: its count) */
+    uint16_t pending_match_size;
+    uint8_t conf;                   /* header byte 0 once the header has been seen */
+    uint8_t skip_bytes;             /* bytes of the pending token already delivered (before the header is
+                                       complete: its stashed first byte) */
+    uint8_t flags;                  /* 1 configured, 2 first header byte stashed, 4 last token was FLUSH */
+    uint8_t window_bits_max;        /* capacity of the window buffer behind this state */
+} TampAmdDecoderState;
+
+size_t tamp_amd_decoder_state_size(uint8_t window_bits_max); /* 16 + (1 << window_bits_max) */
+
+/* Replaces tamp_decompressor_init (decompressor.h:83, decompressor.c:331-347) for an object in HOST memory (copy it
+ * to the device afterwards if the array lives there).  conf == NULL: the header comes from the stream.  With a conf
+ * the window is seeded here unless conf->use_custom_dictionary, in which case the caller fills the window bytes
+ * (at state + 16) with the dictionary, as with the reference's window buffer. */
+tamp_res tamp_amd_decoder_state_init(void *state, const TampAmdConf *conf, uint8_t window_bits_max);
+
+int tamp_batch_decompress_resume(void *states, size_t state_stride, uint8_t window_bits_max, const uint8_t *in,
+                                 const uint64_t *in_off, const uint32_t *in_len, uint8_t *out, const uint64_t *out_off,
+                                 const uint32_t *out_cap, uint32_t *out_len, int8_t *status, uint32_t *in_consumed,
+                                 size_t n_streams, int mem, int device, void *stream);
+
 /* ---- single-stream one-shot entry points (the reference's own call shapes) ------------------- */
 
 /*

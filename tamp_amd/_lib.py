@@ -28,6 +28,9 @@ SYMBOLS = (
     "tamp_amd_last_error",
     "tamp_batch_compress",
     "tamp_batch_decompress",
+    "tamp_amd_decoder_state_size",
+    "tamp_amd_decoder_state_init",
+    "tamp_batch_decompress_resume",
     "tamp_amd_compress",
     "tamp_amd_decompress",
     "tamp_amd_compress_segment",
@@ -108,6 +111,12 @@ def load() -> C.CDLL:
     lib.tamp_batch_compress.restype = i32
     lib.tamp_batch_decompress.argtypes = [vp, sz, u8, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, vp]
     lib.tamp_batch_decompress.restype = i32
+    lib.tamp_amd_decoder_state_size.argtypes = [u8]
+    lib.tamp_amd_decoder_state_size.restype = sz
+    lib.tamp_amd_decoder_state_init.argtypes = [vp, C.POINTER(TampAmdConf), u8]
+    lib.tamp_amd_decoder_state_init.restype = C.c_int8
+    lib.tamp_batch_decompress_resume.argtypes = [vp, sz, u8, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, vp]
+    lib.tamp_batch_decompress_resume.restype = i32
     lib.tamp_amd_compress.argtypes = [C.POINTER(TampAmdConf), vp, vp, sz, C.POINTER(sz), vp, sz, i32]
     lib.tamp_amd_compress.restype = C.c_int8
     lib.tamp_amd_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz), i32]

@@ -220,3 +220,49 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
     _lib.check_launch(rc)
     ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
     return BatchResult(out, out_off, out_len, status, consumed, ms)
+
+
+class DecoderBatch:
+    """``n`` resumable decoder objects advanced together, one launch per step (``tamp_batch_decompress_resume``).
+
+    Each object is what the reference's ``TampDecompressor`` is (tamp/_c_src/tamp/decompressor.h:13-57): its state and
+    window survive between steps, so a stream may arrive in pieces of any size and be decoded into output buffers of
+    any size -- e.g. many network connections decoded as their packets come in.  ``step(chunks, out_caps)`` offers
+    object ``i`` the bytes ``chunks[i]`` and ``out_caps[i]`` bytes of room and returns per object the reference's
+    status code (1 output full, 2 input exhausted, negative = error), the bytes produced and the number of input bytes
+    consumed; what was not consumed must be offered again.  ``conf`` = None reads the header from each stream;
+    a ``dictionary`` is placed in every object's window (used by streams whose header has the custom bit).
+    """
+
+    def __init__(self, n: int, *, window_bits: int = 15, conf: Optional[TampAmdConf] = None, dictionary=None,
+                 device: int = 0):
+        lib = _lib.load()
+        self.n, self.window_bits, self.device = n, window_bits, device
+        self.stride = (lib.tamp_amd_decoder_state_size(window_bits) + 15) & ~15
+        if conf is not None and conf.use_custom_dictionary and dictionary is None:
+            raise ValueError("custom dictionary expected")
+        one = np.zeros(self.stride, dtype=np.uint8)
+        if dictionary is not None:  # the window buffer holds the dictionary, as with the reference's object
+            d = _np_u8(dictionary)[: 1 << window_bits]
+            one[16 : 16 + len(d)] = d
+        res = lib.tamp_amd_decoder_state_init(_ptr(one), C.byref(conf) if conf is not None else None, window_bits)
+        if res != _lib.OK:
+            raise ValueError(f"tamp_amd_decoder_state_init -> {res}")
+        self.states = np.ascontiguousarray(np.broadcast_to(one, (n, self.stride)))
+
+    def step(self, chunks: Sequence, out_caps):
+        lib = _lib.load()
+        flat, in_off, in_len = pack_streams(chunks)
+        out_cap = np.ascontiguousarray(np.broadcast_to(np.asarray(out_caps, dtype=np.uint32), (self.n,)))
+        out_off, total = _slab_offsets(out_cap)
+        out = np.zeros(total + 1, dtype=np.uint8)
+        out_len = np.zeros(self.n, dtype=np.uint32)
+        status = np.zeros(self.n, dtype=np.int8)
+        consumed = np.zeros(self.n, dtype=np.uint32)
+        rc = lib.tamp_batch_decompress_resume(_ptr(self.states), self.stride, self.window_bits,
+                                              _ptr(flat if flat.size else np.zeros(1, np.uint8)), _ptr(in_off),
+                                              _ptr(in_len), _ptr(out), _ptr(out_off), _ptr(out_cap), _ptr(out_len),
+                                              _ptr(status), _ptr(consumed), self.n, _lib.MEM_HOST, self.device, None)
+        _lib.check_launch(rc)
+        outs = [out[int(out_off[i]) : int(out_off[i]) + int(out_len[i])].tobytes() for i in range(self.n)]
+        return status, outs, consumed

@@ -24,6 +24,7 @@
 #include "tamp_compress_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
+#include "tamp_decompress_resume_kernel.hpp"
 
 using namespace tamp_amd;
 
@@ -417,6 +418,37 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     return TAMP_OK;
 }
 
+// Resumable decoding: one wavefront per decoder object (tamp_decompress_resume_kernel.hpp).
+int launch_decompress_resume(DeviceCtx* ctx, uint8_t* d_states, size_t stride, uint8_t bits_max, const uint8_t* d_in,
+                             const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out,
+                             const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status,
+                             uint32_t* d_consumed, size_t n_streams, hipStream_t st) {
+    if (n_streams == 0) return TAMP_OK;
+    ResumeArgs ra;
+    DecompressArgs& a = ra.d;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
+    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
+    a.in_consumed = d_consumed;
+    a.dict = nullptr, a.dict_len = 0;  // a custom dictionary is the initial content of the object's window
+    a.seed_dicts = ctx->seed_dicts;
+    a.scratch = nullptr;
+    a.n_streams = (uint32_t)n_streams;
+    a.lds_row = 0;
+    a.max_wbits = bits_max;
+    ra.states = d_states, ra.state_stride = stride;
+    const uint32_t waves = bits_max <= 12 ? 4 : 1;
+    const uint32_t lds = decode_wave_lds(bits_max, waves);
+    size_t groups = (n_streams + waves - 1) / waves;
+    groups = std::min(groups, (size_t)ctx->cu_count * 64);  // grid-stride beyond that
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_resume_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    timing_begin(st);
+    hipLaunchKernelGGL(tamp_decompress_resume_kernel, dim3((uint32_t)groups), dim3(waves * kWave), lds, st, ra);
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
 bool conf_valid(const TampAmdConf* c) {
     return c && c->window >= 8 && c->window <= 15 && c->literal >= 5 && c->literal <= 8;  // compressor.c:208-209
 }
@@ -785,6 +817,87 @@ int tamp_batch_decompress(const uint8_t* dictionary, size_t dictionary_len, uint
     });
 }
 
+size_t tamp_amd_decoder_state_size(uint8_t window_bits_max) {
+    return sizeof(TampAmdDecoderState) + ((size_t)1 << (window_bits_max & 15));
+}
+
+tamp_res tamp_amd_decoder_state_init(void* state, const TampAmdConf* conf, uint8_t window_bits_max) {
+    if (!state) return TAMP_AMD_BAD_ARGUMENT;
+    if (window_bits_max < 8 || window_bits_max > 15) return TAMP_INVALID_CONF;  // decompressor.c:336
+    TampAmdDecoderState* s = static_cast<TampAmdDecoderState*>(state);
+    std::memset(s, 0, sizeof *s);
+    s->window_bits_max = window_bits_max;
+    if (!conf) return TAMP_OK;
+    // tamp_decompressor_populate_from_conf, decompressor.c:304-329
+    if (!conf_valid(conf) || conf->window > window_bits_max) return TAMP_INVALID_CONF;
+    if (!conf->use_custom_dictionary)
+        seed_dictionary_host(reinterpret_cast<unsigned char*>(s + 1), (size_t)1 << conf->window,
+                             conf->extended ? conf->literal : 8);
+    s->conf = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) | ((conf->use_custom_dictionary ? 1 : 0) << 2) |
+                        ((conf->extended ? 1 : 0) << 1) | (conf->dictionary_reset ? 1 : 0));
+    s->flags = 1;
+    return TAMP_OK;
+}
+
+int tamp_batch_decompress_resume(void* states, size_t state_stride, uint8_t window_bits_max, const uint8_t* in,
+                                 const uint64_t* in_off, const uint32_t* in_len, uint8_t* out, const uint64_t* out_off,
+                                 const uint32_t* out_cap, uint32_t* out_len, int8_t* status, uint32_t* in_consumed,
+                                 size_t n_streams, int mem, int device, void* stream) {
+    if (n_streams && (!states || !in_off || !in_len || !out_off || !out_cap || !out_len || !status))
+        return TAMP_AMD_BAD_ARGUMENT;
+    if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    if (window_bits_max < 8 || window_bits_max > 15 || (state_stride & 15) ||
+        state_stride < tamp_amd_decoder_state_size(window_bits_max) || (reinterpret_cast<uintptr_t>(states) & 3))
+        return TAMP_AMD_BAD_ARGUMENT;
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mem == TAMP_AMD_MEM_DEVICE)
+        return launch_decompress_resume(ctx, static_cast<uint8_t*>(states), state_stride, window_bits_max, in, in_off,
+                                        in_len, out, out_off, out_cap, out_len, status, in_consumed, n_streams, st);
+    if (n_streams == 0) return TAMP_OK;
+    uint64_t in_end = 0, out_end = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        in_end = std::max(in_end, in_off[i] + in_len[i]);
+        out_end = std::max(out_end, out_off[i] + out_cap[i]);
+    }
+    DevBuf d_sta, d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_ic;
+    HIP_OK(d_sta.alloc(n_streams * state_stride));
+    HIP_OK(d_in.alloc(in_end + 64));
+    HIP_OK(d_out.alloc(out_end));
+    HIP_OK(d_io.alloc(n_streams * 8));
+    HIP_OK(d_il.alloc(n_streams * 4));
+    HIP_OK(d_oo.alloc(n_streams * 8));
+    HIP_OK(d_oc.alloc(n_streams * 4));
+    HIP_OK(d_ol.alloc(n_streams * 4));
+    HIP_OK(d_ic.alloc(n_streams * 4));
+    HIP_OK(d_st.alloc(n_streams));
+    HIP_OK(hipMemcpyAsync(d_sta.p, states, n_streams * state_stride, hipMemcpyHostToDevice, st));
+    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_streams * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_streams * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_streams * 4, hipMemcpyHostToDevice, st));
+    rc = launch_decompress_resume(ctx, d_sta.as<uint8_t>(), state_stride, window_bits_max, d_in.as<uint8_t>(),
+                                  d_io.as<uint64_t>(), d_il.as<uint32_t>(), d_out.as<uint8_t>(), d_oo.as<uint64_t>(),
+                                  d_oc.as<uint32_t>(), d_ol.as<uint32_t>(), d_st.as<int8_t>(), d_ic.as<uint32_t>(),
+                                  n_streams, st);
+    if (rc != TAMP_OK) return rc;
+    HIP_OK(hipMemcpyAsync(states, d_sta.p, n_streams * state_stride, hipMemcpyDeviceToHost, st));
+    // only what was written goes back: a caller's output buffer is not touched beyond out_len
+    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(status, d_st.p, n_streams, hipMemcpyDeviceToHost, st));
+    if (in_consumed) HIP_OK(hipMemcpyAsync(in_consumed, d_ic.p, n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_streams; i++)
+        if (out_len[i])
+            HIP_OK(hipMemcpyAsync(out + out_off[i], d_out.as<uint8_t>() + out_off[i], out_len[i], hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return TAMP_OK;
+}
+
 tamp_res tamp_amd_compress(const TampAmdConf* conf, const unsigned char* dictionary, unsigned char* output,
                            size_t output_size, size_t* output_written_size, const unsigned char* input,
                            size_t input_size, int device) {
@@ -853,16 +966,12 @@ struct CompressorPriv {  // lives in TampCompressor::private_ (40 bytes); the wi
     uint8_t opened;          // header / append marker already emitted
     uint8_t last_was_flush;  // compressor.h:26
 };
-struct DecompressorPriv {  // lives in TampDecompressor::private_ (16 bytes)
-    uint32_t magic;
-    TampConf conf;
-    uint8_t has_conf, used, window_bits;
-};
-constexpr uint32_t kMagicC = 0x74616d43u, kMagicD = 0x74616d44u;
+// TampDecompressor::private_ (16 bytes) holds a TampAmdDecoderState: the same fields the reference keeps there
+constexpr uint32_t kMagicC = 0x74616d43u;
 static_assert(sizeof(TampConf) == 2, "TampConf must match the reference (common.h:170-182)");
 static_assert(sizeof(TampCompressor) == 48, "TampCompressor must match the reference (compressor.h:13-66)");
 static_assert(sizeof(TampDecompressor) == 24, "TampDecompressor must match the reference (decompressor.h:13-57)");
-static_assert(sizeof(CompressorPriv) <= 40 && sizeof(DecompressorPriv) <= 16, "private state must fit");
+static_assert(sizeof(CompressorPriv) <= 40 && sizeof(TampAmdDecoderState) == 16, "private state must fit");
 int compat_device() {
     const char* e = getenv("TAMP_AMD_DEVICE");
     return e ? atoi(e) : 0;
@@ -1001,45 +1110,43 @@ tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, v
 tamp_res tamp_decompress_stream(TampDecompressor* decompressor, tamp_read_t read_cb, void* read_handle,
                                 tamp_write_t write_cb, void* write_handle, size_t* input_consumed_size,
                                 size_t* output_written_size, tamp_callback_t callback, void* user_data) {
-    // decompressor.c:585-640: pull until EOF, decode, push.  One whole-stream decode on the device.
-    if (input_consumed_size) *input_consumed_size = 0;
-    if (output_written_size) *output_written_size = 0;
-    std::vector<unsigned char> in;
-    constexpr size_t kChunk = 1 << 16;
+    // decompressor.c:585-640: pull a chunk, decode as far as it goes, push, repeat -- the same loop, with work buffers
+    // sized for a device call instead of a microcontroller stack.  Memory stays bounded whatever the stream expands to.
+    size_t consumed_proxy, written_proxy;
+    if (!input_consumed_size) input_consumed_size = &consumed_proxy;
+    if (!output_written_size) output_written_size = &written_proxy;
+    *input_consumed_size = 0, *output_written_size = 0;
+    constexpr size_t kIn = (size_t)1 << 20, kOut = (size_t)8 << 20;
+    std::vector<unsigned char> in(kIn), out(kOut);
+    size_t pos = 0, avail = 0;
+    bool eof = false;
     for (;;) {
-        const size_t at = in.size();
-        in.resize(at + kChunk);
-        int got = read_cb(read_handle, in.data() + at, kChunk);
-        if (got < 0) return TAMP_READ_ERROR;
-        in.resize(at + (size_t)got);
-        if (got == 0) break;
-        if (input_consumed_size) *input_consumed_size = in.size();
+        if (avail == 0 && !eof) {
+            const int got = read_cb(read_handle, in.data(), (int)std::min<size_t>(kIn, INT_MAX));
+            if (got < 0) return TAMP_READ_ERROR;
+            eof = got == 0;
+            pos = 0, avail = (size_t)got;
+            *input_consumed_size += (size_t)got;
+        }
+        size_t chunk_consumed = 0, chunk_written = 0;
+        const tamp_res res = tamp_decompressor_decompress_cb(decompressor, out.data(), kOut, &chunk_written,
+                                                             in.data() + pos, avail, &chunk_consumed, nullptr, nullptr);
+        if (res < TAMP_OK) return res;
+        pos += chunk_consumed, avail -= chunk_consumed;
+        for (size_t at = 0; at < chunk_written;) {
+            const size_t n = std::min(chunk_written - at, (size_t)1 << 30);
+            const int w = write_cb(write_handle, out.data() + at, n);
+            if (w < 0 || (size_t)w != n) return TAMP_WRITE_ERROR;
+            at += n;
+        }
+        *output_written_size += chunk_written;
+        if (res == TAMP_INPUT_EXHAUSTED && eof) break;
         if (callback) {
-            int cb = callback(user_data, in.size(), 0);
+            const int cb = callback(user_data, *input_consumed_size, 0);
             if (cb) return (tamp_res)cb;
         }
     }
-    std::vector<unsigned char> out(std::max<size_t>(4096, in.size() * 8));
-    for (;;) {
-        TampDecompressor d = *decompressor;  // a retry with a larger buffer starts from the same object state
-        size_t written = 0, consumed = 0;
-        tamp_res r = tamp_decompressor_decompress_cb(&d, out.data(), out.size(), &written, in.data(), in.size(),
-                                                     &consumed, nullptr, nullptr);
-        if (r == TAMP_OUTPUT_FULL) {
-            out.resize(out.size() * 4);
-            continue;
-        }
-        *decompressor = d;
-        if (r < 0) return r;
-        for (size_t at = 0; at < written;) {
-            const size_t n = std::min(written - at, kChunk);
-            int w = write_cb(write_handle, out.data() + at, n);
-            if (w < 0 || (size_t)w != n) return TAMP_WRITE_ERROR;
-            at += n;
-            if (output_written_size) *output_written_size = at;
-        }
-        return TAMP_OK;
-    }
+    return TAMP_OK;
 }
 
 // Built-in I/O handlers (common.c:92-132): plain host adaptors, no codec work.
@@ -1093,74 +1200,63 @@ tamp_res tamp_decompressor_init(TampDecompressor* decompressor, const TampConf* 
     if (window_bits < 8 || window_bits > 15) return TAMP_INVALID_CONF;  // decompressor.c:336
     std::memset(decompressor, 0, sizeof *decompressor);
     decompressor->window = window;
-    DecompressorPriv* p = reinterpret_cast<DecompressorPriv*>(decompressor->private_);
-    p->magic = kMagicD, p->window_bits = window_bits, p->used = 0, p->has_conf = conf != nullptr;
-    if (conf) {
-        if (conf->window < 8 || conf->window > 15 || conf->literal < 5 || conf->literal > 8) return TAMP_INVALID_CONF;
-        if (conf->window > window_bits) return TAMP_INVALID_CONF;  // decompressor.c:311
-        p->conf = *conf;
-    }
+    TampAmdDecoderState* s = reinterpret_cast<TampAmdDecoderState*>(decompressor->private_);
+    s->window_bits_max = window_bits;
+    if (!conf) return TAMP_OK;
+    // tamp_decompressor_populate_from_conf, decompressor.c:304-329
+    if (conf->window < 8 || conf->window > 15 || conf->literal < 5 || conf->literal > 8) return TAMP_INVALID_CONF;
+    if (conf->window > window_bits) return TAMP_INVALID_CONF;
+    if (!conf->use_custom_dictionary)
+        seed_dictionary_host(window, (size_t)1 << conf->window, conf->extended ? conf->literal : 8);
+    s->conf = (uint8_t)(((conf->window - 8) << 5) | ((conf->literal - 5) << 3) | (conf->use_custom_dictionary << 2) |
+                        (conf->extended << 1) | conf->dictionary_reset);
+    s->flags = 1;
     return TAMP_OK;
 }
 
 tamp_res tamp_decompressor_decompress_cb(TampDecompressor* decompressor, unsigned char* output, size_t output_size,
                                          size_t* output_written_size, const unsigned char* input, size_t input_size,
                                          size_t* input_consumed_size, tamp_callback_t callback, void* user_data) {
+    // One call of the reference's (decompressor.c:371-578) = one step of the resumable device decoder on this object:
+    // state from private_, window from the caller's buffer, both written back afterwards.
     if (output_written_size) *output_written_size = 0;
     if (input_consumed_size) *input_consumed_size = 0;
-    DecompressorPriv* p = reinterpret_cast<DecompressorPriv*>(decompressor->private_);
-    if (p->magic != kMagicD) return TAMP_ERROR;
-    if (p->used) {
-        if (input_size == 0) return TAMP_INPUT_EXHAUSTED;  // "nothing more to do" after the one whole-stream call
-        snprintf(t_last_error, sizeof t_last_error,
-                 "tamp_decompressor_decompress: resuming a stream needs state carry-over (not in this release)");
-        return TAMP_ERROR;
-    }
-    // the stream as the kernel wants it: header first.  When init was given a conf the caller's input starts after
-    // the header (tamp/_c_decompressor.pyx:50-75): put one back in front.
-    std::vector<unsigned char> buf;
-    const unsigned char* src = input;
-    size_t n = input_size, hdr = 0;
-    bool custom;
-    if (p->has_conf) {
-        hdr = 1 + (p->conf.dictionary_reset ? 1 : 0);
-        buf.resize(hdr + input_size);
-        buf[0] = (unsigned char)(((p->conf.window - 8) << 5) | ((p->conf.literal - 5) << 3) |
-                                 (p->conf.use_custom_dictionary << 2) | (p->conf.extended << 1) |
-                                 p->conf.dictionary_reset);
-        if (hdr == 2) buf[1] = 0;
-        if (input_size) std::memcpy(buf.data() + hdr, input, input_size);
-        src = buf.data(), n = buf.size();
-        custom = p->conf.use_custom_dictionary;
-    } else {
-        custom = input_size > 0 && ((input[0] >> 2) & 1);
-    }
-    const size_t dict_len = custom ? (size_t)1 << p->window_bits : 0;  // the caller's window holds the dictionary
+    TampAmdDecoderState* s = reinterpret_cast<TampAmdDecoderState*>(decompressor->private_);
+    const uint8_t bits_max = s->window_bits_max;
+    if (bits_max < 8 || bits_max > 15 || !decompressor->window) return TAMP_ERROR;  // not initialised
+    const size_t wcap = (size_t)1 << bits_max;
+    // before the header is known the whole buffer may hold a custom dictionary; afterwards 1 << window bytes are live
+    const size_t wlive = (s->flags & 1) ? (size_t)1 << (((s->conf >> 5) & 7) + 8) : wcap;
+    std::vector<unsigned char> slot(sizeof(TampAmdDecoderState) + wcap);
+    std::memcpy(slot.data(), s, sizeof *s);
+    std::memcpy(slot.data() + sizeof *s, decompressor->window, wlive);
+    const uint64_t zero = 0;
+    static unsigned char empty = 0;
     size_t written = 0, consumed = 0;
-    tamp_res r;
-    {
-        if (n > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
-        const uint64_t zero = 0;
-        const uint32_t ilen = (uint32_t)n;
-        const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+    int8_t st = TAMP_ERROR;
+    for (;;) {  // one device step per 256 MiB of input / 1 GiB of output room (the kernel's counters are 32 bits wide)
+        const uint32_t ilen = (uint32_t)std::min<size_t>(input_size - consumed, 0x10000000u);
+        const uint32_t ocap = (uint32_t)std::min<size_t>(output_size - written, 0x40000000u);
         uint32_t olen = 0, icons = 0;
-        int8_t st = TAMP_ERROR;
-        static const unsigned char empty = 0;
-        // max_window_bits = the caller's buffer size: a header asking for more is TAMP_INVALID_CONF (decompressor.c:311)
-        int rc = tamp_batch_decompress(custom ? decompressor->window : nullptr, dict_len, p->window_bits,
-                                       n ? src : &empty, &zero, &ilen, output, &zero, &ocap, &olen, &st, &icons, 1,
-                                       TAMP_AMD_MEM_HOST, compat_device(), nullptr);
-        r = rc != TAMP_OK ? (tamp_res)rc : st;
-        written = olen, consumed = icons;
+        const int rc = tamp_batch_decompress_resume(slot.data(), slot.size(), bits_max, ilen ? input + consumed : &empty,
+                                                    &zero, &ilen, ocap ? output + written : &empty, &zero, &ocap, &olen,
+                                                    &st, &icons, 1, TAMP_AMD_MEM_HOST, compat_device(), nullptr);
+        if (rc != TAMP_OK) return (tamp_res)rc;
+        written += olen, consumed += icons;
+        const bool more_in = st == TAMP_INPUT_EXHAUSTED && icons == ilen && consumed < input_size;
+        const bool more_out = st == TAMP_OUTPUT_FULL && olen == ocap && written < output_size;
+        if (!more_in && !more_out) break;
     }
+    std::memcpy(s, slot.data(), sizeof *s);
+    const size_t wnow = (s->flags & 1) ? (size_t)1 << (((s->conf >> 5) & 7) + 8) : 0;
+    if (wnow) std::memcpy(decompressor->window, slot.data() + sizeof *s, wnow);
     if (output_written_size) *output_written_size = written;
-    if (input_consumed_size) *input_consumed_size = consumed > hdr ? consumed - hdr : 0;
-    p->used = 1;
-    if (r >= 0 && callback) {
-        int cb = callback(user_data, input_size, input_size);
+    if (input_consumed_size) *input_consumed_size = consumed;
+    if (st >= 0 && callback) {
+        const int cb = callback(user_data, consumed, input_size);
         if (cb) return (tamp_res)cb;
     }
-    return r;
+    return st;
 }
 
 tamp_res tamp_decompressor_decompress(TampDecompressor* decompressor, unsigned char* output, size_t output_size,

@@ -377,7 +377,10 @@ def test_reference_named_c_api(ta, oracle):
         cbuf = (C.c_ubyte * len(want)).from_buffer_copy(want)
         r = lib.tamp_decompressor_decompress(d, back, 4096, C.byref(written), cbuf, len(want), C.byref(consumed))
         assert (r, bytes(back[: written.value]), consumed.value) == (2, data, len(want))
-        # ... or handed to init, with the input starting after the header (the Cython binding's way)
+        # ... or handed to init, with the input starting after the header (the Cython binding's way); the window buffer
+        # was decoded into, as with the reference, so a custom dictionary has to be put back first
+        if dic is not None:
+            C.memmove(window, dic, W)
         d = decomp_t()
         assert lib.tamp_decompressor_init(d, C.byref(conf), window, conf.window) == 0
         cbuf = (C.c_ubyte * (len(want) - 1)).from_buffer_copy(want[1:])
@@ -702,3 +705,140 @@ def test_host_memory_batches_run_as_overlapping_chunks(ta, oracle, monkeypatch):
     for t in threads:
         t.join()
     assert not errs, errs
+
+
+def _resume_golden(rec):
+    conf = tuple(rec["conf"]) if rec["conf"] is not None else None
+    dic = unb64(rec["dictionary"]) if rec["dictionary"] else None
+    return (unb64(rec["data"]), [tuple(s) for s in rec["script"]], conf, dic,
+            [(r, unb64(out), k) for r, out, k in rec["calls"]])
+
+
+def _drive_decoder_batch(ta, jobs, window_bits):
+    """jobs: [(data, script, conf, dictionary)] sharing conf-kind and dictionary per DecoderBatch is not required by the
+    kernel, but DecoderBatch gives every object the same initial state: group jobs accordingly before calling."""
+    from tamp_amd import _lib
+
+    data0, _, conf, dic = jobs[0]
+    tconf = None
+    if conf is not None:
+        tconf = _lib.TampAmdConf(window=conf[0], literal=conf[1], use_custom_dictionary=int(conf[2]), extended=int(conf[3]),
+                                 dictionary_reset=int(conf[4]))
+    try:
+        batch = ta.DecoderBatch(len(jobs), window_bits=window_bits, conf=tconf, dictionary=dic)
+    except ValueError as e:
+        return int(str(e).rsplit(" ", 1)[1]), None
+    pos = [0] * len(jobs)
+    calls = [[] for _ in jobs]
+    for step in range(max(len(j[1]) for j in jobs)):
+        chunks, caps = [], []
+        for i, (data, script, _, _) in enumerate(jobs):
+            take, cap = script[step] if step < len(script) else (0, 0)
+            chunks.append(data[pos[i] : pos[i] + take]), caps.append(cap)
+        status, outs, consumed = batch.step(chunks, np.array(caps, dtype=np.uint32))
+        for i, (data, script, _, _) in enumerate(jobs):
+            if step < len(script):
+                calls[i].append((int(status[i]), outs[i], int(consumed[i])))
+                pos[i] += int(consumed[i])
+    return 0, calls
+
+
+def test_decoder_resume_golden_scripts(ta):
+    """Decoder objects advanced call by call on the device (tamp_batch_decompress_resume) against what one reference
+    TampDecompressor returned for the same calls (tests/golden/decoder_resume.json): status, bytes and consumed count
+    of every call -- tokens cut short by a full output buffer, by the end of the input, headers split over calls."""
+    recs = load_golden("decoder_resume.json")
+    groups = {}
+    for rec in recs:
+        data, script, conf, dic, want = _resume_golden(rec)
+        groups.setdefault((conf, dic, rec["window_bits"]), []).append((rec, data, script, want))
+    for (conf, dic, wb), items in groups.items():
+        r0, calls = _drive_decoder_batch(ta, [(d, s, conf, dic) for _, d, s, _ in items], wb)
+        for k, (rec, _, _, want) in enumerate(items):
+            assert r0 == rec["init"], rec["name"]
+            if calls is not None:
+                assert calls[k] == want, rec["name"]
+
+
+def test_decoder_resume_differential_vs_oracle(ta, oracle):
+    """Random streams (flush tokens, dictionary resets, corrupted bytes), random chunking of input and output room,
+    hundreds of objects per launch: every call equals the oracle's resumable decoder."""
+    from tamp_amd import workloads as wl
+
+    rng = random.Random(4242)
+    for rnd in range(6):
+        w = rng.randrange(8, 16)
+        wb = rng.choice([15, w, w])
+        lit = rng.choice([7, 8, 8])
+        jobs = []
+        for j in range(120):
+            ext = rng.random() < 0.7
+            dr = rng.random() < 0.3
+            x = _rand_inputs(rng, wl, rng.choice([0, 1, 40, 700, 3000, rng.randrange(1, 5000)]))
+            if lit < 8:
+                x = bytes(b & 127 for b in x)
+            ops, pos = [], 0
+            while pos < len(x):
+                k = rng.randrange(1, 900)
+                ops.append(("write", x[pos : pos + k]))
+                pos += k
+                u = rng.random()
+                if u < 0.15:
+                    ops.append(("flush", rng.random() < 0.7))
+                elif u < 0.22 and dr:
+                    ops.append(("reset",))
+            ops.append(("close",))
+            st, blob = oracle.stream_script(ops, window=w, literal=lit, extended=ext, dictionary_reset=dr)
+            assert st == 0
+            if rng.random() < 0.2 and len(blob) > 3:
+                b = bytearray(blob)
+                b[rng.randrange(1, len(b))] ^= 1 << rng.randrange(8)
+                blob = bytes(b)
+            script = [(rng.choice([0, 1, 2, 3, 5, 9, 40, 1000, 100000]), rng.choice([0, 1, 2, 3, 7, 20, 64, 300, 5000]))
+                      for _ in range(rng.randrange(1, 50))]
+            script.append((1 << 20, 1 << 15))
+            jobs.append((blob, script, None, None))
+        r0, calls = _drive_decoder_batch(ta, jobs, wb)
+        assert r0 == 0
+        for j, (blob, script, _, _) in enumerate(jobs):
+            want0, want = oracle.decode_script(blob, script, window_bits=wb)
+            assert want0 == 0 and calls[j] == want, (rnd, j, w, wb, lit)
+
+
+def test_reference_named_decompressor_object_resumes(ta, oracle):
+    """tamp_decompressor_decompress under the reference's name, called the way its own stream loop and the Cython
+    wrapper call it (decompressor.c:585-640, tamp/_c_decompressor.pyx:77-129): small inputs, small output buffers,
+    state in the caller's 24-byte object and window buffer."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+    sz = C.POINTER(C.c_size_t)
+    lib.tamp_decompressor_init.restype = C.c_int8
+    lib.tamp_decompressor_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8]
+    lib.tamp_decompressor_decompress.restype = C.c_int8
+    lib.tamp_decompressor_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_void_p, C.c_size_t, sz]
+    rng = random.Random(5)
+    text = wl.synth_text(1, 5000, first_index=3)[0].tobytes()
+    runs = wl.lcg_runs(1, 3000, first_index=2)[0].tobytes()
+    for plain, w in ((text, 10), (runs, 9), (bytes(900) + text[:600], 12)):
+        st, blob = oracle.compress(plain, window=w)
+        assert st == 0
+        script = [(rng.choice([1, 3, 17, 200]), rng.choice([1, 5, 33, 400])) for _ in range(4000)]
+        want0, want = oracle.decode_script(blob, script, window_bits=w)
+        obj, window = (C.c_ubyte * 24)(), (C.c_ubyte * (1 << w))()
+        assert lib.tamp_decompressor_init(obj, None, window, w) == want0 == 0
+        pos, back = 0, bytearray()
+        for (take, cap), (wst, wout, wcons) in zip(script, want):
+            chunk = blob[pos : pos + take]
+            out = (C.c_ubyte * max(cap, 1))()
+            nw, nc = C.c_size_t(0), C.c_size_t(0)
+            got = lib.tamp_decompressor_decompress(obj, out, cap, C.byref(nw), chunk, len(chunk), C.byref(nc))
+            assert (got, bytes(out[: nw.value]), nc.value) == (wst, wout, wcons), (w, pos)
+            pos += nc.value
+            back += bytes(out[: nw.value])
+            if pos == len(blob) and got == 2 and nw.value == 0:
+                break
+        assert bytes(back) == plain
