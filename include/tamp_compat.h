@@ -29,10 +29,12 @@
  * tamp_compressor_compress without a flush): there is no place in the 48-byte object to park unflushed input,
  * and the library does not allocate on the caller's behalf ("no heap use").
  *
- * Decompressor objects decode ONE complete stream per object (conf from the header, or passed to init with the
- * input starting after the header, as tamp/_c_decompressor.pyx:50-75 does); a second call with more input
- * returns TAMP_ERROR.  tamp_decompress_stream pulls the whole input first, so it has no such limit.
- * Progress callbacks are invoked per pulled chunk (stream API) or once at completion.
+ * Decompressor objects resume like the reference's: the 16 private bytes hold the same fields (TampAmdDecoderState in
+ * tamp_amd.h), the window lives in the caller's buffer, and each tamp_decompressor_decompress[_cb] call is one step of
+ * the device decoder -- any split of the input, any output room, TAMP_OUTPUT_FULL / TAMP_INPUT_EXHAUSTED and the
+ * written / consumed counts exactly as decompressor.c:371-578 returns them.  tamp_decompress_stream is the reference's
+ * loop over that call (decompressor.c:585-640) with larger work buffers.
+ * The progress callback is invoked once per call (stream API: once per pulled chunk).
  */
 #ifndef TAMP_COMPAT_H
 #define TAMP_COMPAT_H
