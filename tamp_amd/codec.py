@@ -14,6 +14,8 @@ import ctypes as C
 from io import BytesIO
 from typing import Union
 
+import numpy as np
+
 from . import _lib
 from ._lib import TampAmdConf
 
@@ -162,8 +164,11 @@ def compress(data: Union[bytes, str], *args, **kwargs) -> bytes:
 class Decompressor:
     """``tamp.Decompressor`` (tamp/_c_decompressor.pyx:12-176).
 
-    The whole stream read so far is decoded on the device; ``read(n)`` / ``readinto`` hand out slices, so the
-    restricted-read and stream-break behaviours of the reference's tests hold.
+    One resumable decoder object on the device (``tamp_batch_decompress_resume``): ``readinto`` /
+    ``read(n)`` pull input from ``f`` a chunk at a time and decode exactly as much as the caller's buffer takes, the
+    object's state and window carrying over between calls -- the reference's loop, so its restricted-read and
+    stream-break behaviours hold and memory stays bounded.  ``read()`` reads the rest of ``f`` first and decodes it in
+    a few large steps.
     """
 
     def __init__(self, f, *, dictionary=None, device: int = 0):
@@ -193,52 +198,73 @@ class Decompressor:
             raise ValueError
         if dictionary is not None and len(dictionary) < (1 << conf.window):
             raise ValueError("Dictionary-window size mismatch.")
-        self._dictionary = bytes(dictionary[: 1 << conf.window]) if dictionary is not None else None
-        self._compressed = bytearray(header)
-        self._out = bytearray()
-        self._pos = 0
+        # the decoder object: 16 bytes of state + its window (tamp_decompressor_init with the conf, :72-75)
+        self._window_bits = conf.window
+        self._stride = (lib.tamp_amd_decoder_state_size(conf.window) + 15) & ~15
+        self._slot = np.zeros(self._stride, dtype=np.uint8)
+        if dictionary is not None:
+            self._slot[16 : 16 + (1 << conf.window)] = np.frombuffer(bytes(dictionary[: 1 << conf.window]), dtype=np.uint8)
+        res = lib.tamp_amd_decoder_state_init(self._slot.ctypes.data_as(C.c_void_p), C.byref(conf), conf.window)
+        if res < 0:
+            _raise_for(res)
+        self._pending = b""  # input read from f and not consumed yet
 
-    def _decode_all(self):
-        more = self.f.read()
-        if not more and self._out_valid:
-            return
-        self._compressed += more
+    def _step(self, room: int):
+        """One tamp_decompressor_decompress call: offer the pending input and `room` bytes of output."""
         lib = _lib.load()
-        n = len(self._compressed)
-        src = (C.c_ubyte * n).from_buffer_copy(bytes(self._compressed))
-        d = (C.c_ubyte * len(self._dictionary)).from_buffer_copy(self._dictionary) if self._dictionary else None
-        cap = max(4096, 8 * n)
-        while True:
-            out = (C.c_ubyte * cap)()
-            written, consumed = C.c_size_t(0), C.c_size_t(0)
-            res = lib.tamp_amd_decompress(d, len(self._dictionary) if self._dictionary else 0, out, cap,
-                                          C.byref(written), src, n, C.byref(consumed), self._device)
-            if res == _lib.OUTPUT_FULL:
-                cap *= 4
-                continue
-            if res < 0:
+        n = len(self._pending)
+        src = np.frombuffer(self._pending, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        out = np.empty(max(room, 1), dtype=np.uint8)
+        zero = np.zeros(1, dtype=np.uint64)
+        in_len, out_cap = np.array([n], dtype=np.uint32), np.array([room], dtype=np.uint32)
+        out_len, consumed = np.zeros(1, dtype=np.uint32), np.zeros(1, dtype=np.uint32)
+        status = np.zeros(1, dtype=np.int8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = lib.tamp_batch_decompress_resume(p(self._slot), self._stride, self._window_bits, p(src), p(zero), p(in_len),
+                                              p(out), p(zero), p(out_cap), p(out_len), p(status), p(consumed), 1,
+                                              _lib.MEM_HOST, self._device, None)
+        _lib.check_launch(rc)
+        self._pending = self._pending[int(consumed[0]) :]
+        return int(status[0]), out[: int(out_len[0])]
+
+    def readinto(self, buf: bytearray) -> int:  # tamp/_c_decompressor.pyx:77-129
+        size, pos = len(buf), 0
+        while size:
+            res, out = self._step(min(size, 1 << 30))
+            buf[pos : pos + len(out)] = out.tobytes()
+            pos += len(out)
+            size -= len(out)
+            if res == _lib.INPUT_EXHAUSTED:
+                chunk = self.f.read(CHUNK_SIZE)
+                if not chunk:
+                    break
+                self._pending += bytes(chunk)
+            elif res < 0:
                 _raise_for(res)
-            break
-        self._out = bytearray(out[: written.value])
-        self._out_valid = True
+        return pos
 
-    _out_valid = False
-
-    def readinto(self, buf: bytearray) -> int:
-        self._decode_all()
-        chunk = self._out[self._pos : self._pos + len(buf)]
-        buf[: len(chunk)] = chunk
-        self._pos += len(chunk)
-        return len(chunk)
-
-    def read(self, size: int = -1) -> bytearray:
+    def read(self, size: int = -1) -> bytearray:  # tamp/_c_decompressor.pyx:131-164
         if size == 0:
             return bytearray()
-        self._decode_all()
-        end = len(self._out) if size < 0 else min(len(self._out), self._pos + size)
-        chunk = bytearray(self._out[self._pos : end])
-        self._pos = end
-        return chunk
+        if size > 0:
+            buf = bytearray(size)
+            n = self.readinto(buf)
+            del buf[n:]
+            return buf
+        self._pending += bytes(self.f.read())  # to the end of the stream: everything at once, a few large steps
+        out = []
+        room = max(CHUNK_SIZE, 8 * len(self._pending))
+        while True:
+            buf = bytearray(room)
+            n = self.readinto(buf)
+            if n < room:
+                del buf[n:]
+                if n:
+                    out.append(buf)
+                break
+            out.append(buf)
+            room <<= 1
+        return out[0] if len(out) == 1 else bytearray(b"".join(out))
 
     def close(self):
         if self._close_f_on_close:
