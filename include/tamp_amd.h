@@ -58,6 +58,11 @@ enum {
     TAMP_AMD_MEM_DEVICE = 1, /* device pointers on `device`: zero-copy, kernels only */
 };
 
+/* `device` argument of tamp_batch_compress / tamp_batch_decompress with host memory: cut the batch into one contiguous
+ * range of streams per visible HIP device (balanced by input bytes) and run the ranges concurrently, one host thread
+ * and one device each.  Streams are independent: no data moves between devices. */
+#define TAMP_AMD_ALL_DEVICES (-1)
+
 /* Page-locked host memory for TAMP_AMD_MEM_HOST calls, for callers that do not link the HIP runtime themselves
  * (cgo / JNI / ctypes).  Not in the reference: its buffers never leave the CPU.  NULL when the allocation fails. */
 void *tamp_amd_host_alloc(size_t bytes);

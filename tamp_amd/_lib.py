@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtamp_amd.so")
 OK, OUTPUT_FULL, INPUT_EXHAUSTED = 0, 1, 2
 ERROR, EXCESS_BITS, INVALID_CONF, OOB = -1, -2, -3, -4
 NO_DEVICE, BAD_ARGUMENT = -20, -21
+ALL_DEVICES = -1  # include/tamp_amd.h TAMP_AMD_ALL_DEVICES
 WINDOW_BITS_EXACT = 0x80  # include/tamp_amd.h: TAMP_AMD_WINDOW_BITS_EXACT
 MEM_HOST, MEM_DEVICE = 0, 1
 

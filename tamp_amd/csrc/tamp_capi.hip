@@ -658,6 +658,58 @@ size_t env_or(const char* name, size_t dflt) {  // tuning knobs of the host-memo
     return v > 0 ? (size_t)v : dflt;
 }
 
+// TAMP_AMD_ALL_DEVICES with host memory: the streams are independent, so the batch is cut into one contiguous range
+// per visible device, balanced by input bytes, and each range runs the host-memory path of
+// its device on its own host thread.  No data moves between devices; results land in the caller's arrays directly.
+int device_fanout_count() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return 0;
+    const char* e = getenv("TAMP_AMD_FANOUT");  // tests: more shards than devices (they share device i % count)
+    const int forced = e ? atoi(e) : 0;
+    return forced > 0 ? forced : count;
+}
+
+template <class Call>  // Call(device, first_stream, count) -> library-level return code
+int fan_out_over_devices(const uint32_t* in_len, size_t n_streams, const Call& call) {
+    const int shards = device_fanout_count();
+    int devices = 0;
+    (void)hipGetDeviceCount(&devices);
+    if (shards < 1 || devices < 1) {
+        snprintf(t_last_error, sizeof t_last_error, "no HIP device visible");
+        return TAMP_AMD_NO_DEVICE;
+    }
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_streams; i++) total += in_len[i];
+    std::vector<size_t> cut(shards + 1, n_streams);
+    cut[0] = 0;
+    {
+        uint64_t run = 0;
+        size_t i = 0;
+        for (int r = 1; r < shards; r++) {
+            const uint64_t target = total / (uint64_t)shards * (uint64_t)r;
+            while (i < n_streams && (total ? run < target : i < n_streams * (size_t)r / (size_t)shards)) run += in_len[i++];
+            cut[r] = i;
+        }
+    }
+    std::vector<int> rcs(shards, TAMP_OK);
+    std::vector<std::string> msgs(shards);
+    std::vector<std::thread> workers;
+    for (int r = 0; r < shards; r++) {
+        if (cut[r + 1] == cut[r]) continue;
+        workers.emplace_back([&, r] {
+            rcs[r] = call(r % devices, cut[r], cut[r + 1] - cut[r]);
+            if (rcs[r] != TAMP_OK) msgs[r] = t_last_error;
+        });
+    }
+    for (std::thread& w : workers) w.join();
+    for (int r = 0; r < shards; r++)
+        if (rcs[r] != TAMP_OK) {
+            snprintf(t_last_error, sizeof t_last_error, "shard %d: %s", r, msgs[r].c_str());
+            return rcs[r];
+        }
+    return TAMP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -743,6 +795,15 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         return TAMP_AMD_BAD_ARGUMENT;
     if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
     if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    if (device == TAMP_AMD_ALL_DEVICES) {
+        if (mem != TAMP_AMD_MEM_HOST) return TAMP_AMD_BAD_ARGUMENT;  // device pointers belong to one device
+        if (!max_in_len)
+            for (size_t i = 0; i < n_streams; i++) max_in_len = std::max(max_in_len, in_len[i]);
+        return fan_out_over_devices(in_len, n_streams, [&](int dev, size_t i0, size_t cnt) {
+            return tamp_batch_compress(conf, dictionary, in, in_off + i0, in_len + i0, out, out_off + i0, out_cap + i0,
+                                       out_len + i0, status + i0, cnt, max_in_len, mem, dev, nullptr);
+        });
+    }
     DeviceCtx* ctx = nullptr;
     int rc = get_ctx(device, &ctx);
     if (rc != TAMP_OK) return rc;
@@ -791,6 +852,14 @@ int tamp_batch_decompress(const uint8_t* dictionary, size_t dictionary_len, uint
     if (n_streams && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return TAMP_AMD_BAD_ARGUMENT;
     if (n_streams > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
     if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    if (device == TAMP_AMD_ALL_DEVICES) {
+        if (mem != TAMP_AMD_MEM_HOST) return TAMP_AMD_BAD_ARGUMENT;
+        return fan_out_over_devices(in_len, n_streams, [&](int dev, size_t i0, size_t cnt) {
+            return tamp_batch_decompress(dictionary, dictionary_len, max_window_bits, in, in_off + i0, in_len + i0, out,
+                                         out_off + i0, out_cap + i0, out_len + i0, status + i0,
+                                         in_consumed ? in_consumed + i0 : nullptr, cnt, mem, dev, nullptr);
+        });
+    }
     DeviceCtx* ctx = nullptr;
     int rc = get_ctx(device, &ctx);
     if (rc != TAMP_OK) return rc;

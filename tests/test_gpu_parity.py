@@ -688,6 +688,18 @@ def test_host_memory_batches_run_as_overlapping_chunks(ta, oracle, monkeypatch):
     for k, j in enumerate(perm):
         assert int(res.status[k]) == want8[j][0] and res.stream(k) == want8[j][1], (k, j)
 
+    # one contiguous shard of streams per device, a host thread each (TAMP_AMD_ALL_DEVICES; here three shards that
+    # share the one visible device)
+    monkeypatch.setenv("TAMP_AMD_FANOUT", "3")
+    res = ta.compress_batch(datas, window=10, device=_lib.ALL_DEVICES)
+    for j, (st, blob) in enumerate(want8):
+        assert int(res.status[j]) == st and res.stream(j) == blob, j
+    back = ta.decompress_batch([b for _, b in want8], out_cap=np.array([len(x) + 8 for x in datas], dtype=np.uint32),
+                               device=_lib.ALL_DEVICES)
+    for j, x in enumerate(datas):
+        assert int(back.status[j]) == 2 and back.stream(j) == x, j
+    monkeypatch.delenv("TAMP_AMD_FANOUT")
+
     errs = []
 
     def worker(lo, hi):
