@@ -194,6 +194,59 @@ int tamp_batch_decompress_resume(void *states, size_t state_stride, uint8_t wind
                                  const uint32_t *out_cap, uint32_t *out_len, int8_t *status, uint32_t *in_consumed,
                                  size_t n_streams, int mem, int device, void *stream);
 
+/* ---- compressor objects below flush granularity -----------------------------------------------
+ *
+ * What TampCompressor is in the reference (compressor.h:13-66): a 16-byte input ring that is parsed only while it is
+ * full, an RLE run / extended match that may still be growing, a lazily cached match, up to 31 pending output bits --
+ * next to the window.  tamp_batch_compress_resume runs one of the reference's calls on every object of an array
+ * (same layout rule as the decoder objects: state, then the window of 1 << window_bits_max bytes; state_stride a
+ * multiple of 16 and >= tamp_amd_encoder_state_size):
+ *   TAMP_AMD_OP_POLL                tamp_compressor_poll (compressor.h:142)            one parse step
+ *   TAMP_AMD_OP_COMPRESS            tamp_compressor_compress_cb (compressor.h:227)     sink + poll while the ring fills
+ *   TAMP_AMD_OP_FLUSH               tamp_compressor_flush (compressor.h:193)
+ *   TAMP_AMD_OP_COMPRESS_AND_FLUSH  tamp_compressor_compress_and_flush_cb (compressor.h:259)
+ * with the reference's results per object: status (TAMP_OK / TAMP_OUTPUT_FULL / TAMP_EXCESS_BITS), bytes written,
+ * input bytes consumed -- including calls whose output buffer fills up.  Whole segments (everything between two
+ * flush points, known up front) are the batch kernel's job: tamp_batch_compress / tamp_amd_compress_segment.
+ */
+typedef struct TampAmdEncoderState {
+    uint32_t bit_buffer;      /* pending output bits, left aligned (the header sits here after init) */
+    uint16_t window_pos;
+    uint8_t bit_buffer_pos;
+    uint8_t input_size;       /* bytes in the ring (0..16) */
+    uint8_t input_pos;        /* ring read position */
+    uint8_t window;           /* conf: window bits */
+    uint8_t literal;          /* conf: literal bits */
+    uint8_t flags;            /* conf: 1 custom dictionary, 2 extended, 4 dictionary_reset, 8 append, 16 lazy_matching */
+    uint8_t input[16];        /* the ring */
+    int16_t cached_match_index; /* lazy matching: match found for the next position, -1 = none */
+    uint16_t extended_match_position;
+    uint8_t cached_match_size;
+    uint8_t rle_count;
+    uint8_t extended_match_count;
+    uint8_t last_was_flush;
+    uint32_t reserved;
+} TampAmdEncoderState;
+
+enum {
+    TAMP_AMD_OP_POLL = 1,
+    TAMP_AMD_OP_COMPRESS = 2,
+    TAMP_AMD_OP_FLUSH = 3,
+    TAMP_AMD_OP_COMPRESS_AND_FLUSH = 4,
+};
+
+size_t tamp_amd_encoder_state_size(uint8_t window_bits_max); /* 40 + (1 << window_bits_max) */
+
+/* Replaces tamp_compressor_init (compressor.h:84, compressor.c:191-244) for an object in HOST memory: header (or the
+ * append marker) into the bit buffer, window seeded unless conf->use_custom_dictionary (then the caller fills the
+ * window bytes at state + 40).  `append` as TampConf.append (compressor.c:227-235). */
+tamp_res tamp_amd_encoder_state_init(void *state, const TampAmdConf *conf, int append, uint8_t window_bits_max);
+
+int tamp_batch_compress_resume(void *states, size_t state_stride, uint8_t window_bits_max, int op, int write_token,
+                               const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint8_t *out,
+                               const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int8_t *status,
+                               uint32_t *in_consumed, size_t n_objects, int mem, int device, void *stream);
+
 /* ---- single-stream one-shot entry points (the reference's own call shapes) ------------------- */
 
 /*

@@ -7,6 +7,8 @@
  *   TampCompressor (48 B), TampDecompressor (24 B)  compressor.h:13-66, decompressor.h:13-57 -- caller-allocated;
  *                                               only the `window` pointer is public, the rest is private here too
  *   tamp_compressor_init ...................... compressor.h:84
+ *   tamp_compressor_sink / _full / _poll ...... compressor.h:101,154,142
+ *   tamp_compressor_compress[_cb] ............. compressor.h:227,244
  *   tamp_compressor_compress_and_flush[_cb] ... compressor.h:259,280-286
  *   tamp_compressor_flush ..................... compressor.h:193
  *   tamp_compressor_reset_dictionary .......... compressor.h:217
@@ -21,13 +23,14 @@
  *
  * Every codec call is a launch on HIP device $TAMP_AMD_DEVICE (default 0); there is no CPU code path.
  *
- * Compressor objects are stateful the way the reference's are at FLUSH granularity: the window lives in the
- * caller's buffer, window_pos / last_was_flush in the object, and each tamp_compressor_compress_and_flush call
- * (any write_token), tamp_compressor_flush, tamp_compressor_reset_dictionary or tamp_compress_stream encodes one
- * segment on the device -- any number of them per object, bytes identical to the reference's.  What is NOT
- * offered is the 16-byte ring interface below flush granularity (tamp_compressor_sink / _poll / _full and
- * tamp_compressor_compress without a flush): there is no place in the 48-byte object to park unflushed input,
- * and the library does not allocate on the caller's behalf ("no heap use").
+ * Compressor objects hold the reference's own state (TampAmdEncoderState in tamp_amd.h: bit buffer, 16-byte input
+ * ring, pending RLE run / extended match, lazy cache, last_was_flush) in their 40 private bytes and the window in the
+ * caller's buffer, so every call means what it means in the reference at any granularity: tamp_compressor_sink /
+ * _full are ring operations on the host, tamp_compressor_poll / _compress[_cb] / _flush / _compress_and_flush[_cb] /
+ * _reset_dictionary run on the device, with the reference's status, written and consumed counts also when the
+ * output buffer is too small.  Calls below flush granularity are parsed token by token by one wavefront
+ * (tamp_compress_resume_kernel.hpp); tamp_compressor_compress_and_flush of 2 KiB or more on an object that is
+ * between segments, and tamp_compress_stream, go through the batch kernel's segment mode.
  *
  * Decompressor objects resume like the reference's: the 16 private bytes hold the same fields (TampAmdDecoderState in
  * tamp_amd.h), the window lives in the caller's buffer, and each tamp_decompressor_decompress[_cb] call is one step of
@@ -91,6 +94,17 @@ int tamp_stream_stdio_read(void *handle, unsigned char *buffer, size_t size);
 int tamp_stream_stdio_write(void *handle, const unsigned char *buffer, size_t size);
 
 tamp_res tamp_compressor_init(TampCompressor *compressor, const TampConf *conf, unsigned char *window);
+void tamp_compressor_sink(TampCompressor *compressor, const unsigned char *input, size_t input_size,
+                          size_t *consumed_size);
+bool tamp_compressor_full(const TampCompressor *compressor);
+tamp_res tamp_compressor_poll(TampCompressor *compressor, unsigned char *output, size_t output_size,
+                              size_t *output_written_size);
+tamp_res tamp_compressor_compress_cb(TampCompressor *compressor, unsigned char *output, size_t output_size,
+                                     size_t *output_written_size, const unsigned char *input, size_t input_size,
+                                     size_t *input_consumed_size, tamp_callback_t callback, void *user_data);
+tamp_res tamp_compressor_compress(TampCompressor *compressor, unsigned char *output, size_t output_size,
+                                  size_t *output_written_size, const unsigned char *input, size_t input_size,
+                                  size_t *input_consumed_size);
 
 tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor *compressor, unsigned char *output, size_t output_size,
                                                size_t *output_written_size, const unsigned char *input,

@@ -387,3 +387,57 @@ class Ref(_Base):
             return r0.value, calls
         finally:
             L.ref_decoder_free(h)
+
+    def encode_script(self, ops, *, window=10, literal=8, extended=True, dictionary=None, dictionary_reset=False,
+                      append=False, lazy_matching=False):
+        """One reference TampCompressor object driven below flush granularity.  ops:
+        ("compress", data, cap) / ("poll", cap) / ("flush", write_token, cap) / ("compress_and_flush", data, write_token, cap)
+        / ("sink", data).  Input that a call does not consume is dropped (the script decides what to offer next).
+        -> (init status, [(status, bytes written, consumed), ...])"""
+        L = self.lib
+        L.ref_stream_new.restype = C.c_void_p
+        L.ref_stream_new.argtypes = [C.c_int] * 7 + [C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_stream_free.argtypes = [C.c_void_p]
+        sz = C.POINTER(C.c_size_t)
+        L.ref_stream_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz]
+        L.ref_stream_full.argtypes = [C.c_void_p]
+        L.ref_stream_poll.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz]
+        L.ref_stream_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, sz, sz]
+        L.ref_stream_compress_and_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, sz, sz,
+                                                    C.c_int]
+        L.ref_stream_flush.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, sz]
+        for fn in ("ref_stream_sink", "ref_stream_full", "ref_stream_poll", "ref_stream_compress",
+                   "ref_stream_compress_and_flush", "ref_stream_flush"):
+            getattr(L, fn).restype = C.c_int
+        dd = _u8(dictionary) if dictionary is not None else None
+        r0 = C.c_int(0)
+        h = L.ref_stream_new(window, literal, int(dictionary is not None), int(extended), int(dictionary_reset),
+                             int(append), int(lazy_matching), _p(dd) if dd is not None else None, C.byref(r0))
+        calls = []
+        try:
+            if r0.value != OK:
+                return r0.value, calls
+            for op in ops:
+                w, k = C.c_size_t(0), C.c_size_t(0)
+                if op[0] == "sink":
+                    a = _u8(op[1])
+                    L.ref_stream_sink(h, _p(a) if len(a) else None, len(a), C.byref(k))
+                    calls.append((OK, b"", k.value))
+                    continue
+                cap = op[-1]
+                out = np.zeros(cap + 1, dtype=np.uint8)
+                if op[0] == "poll":
+                    r = L.ref_stream_poll(h, _p(out), cap, C.byref(w))
+                elif op[0] == "flush":
+                    r = L.ref_stream_flush(h, int(op[1]), _p(out), cap, C.byref(w))
+                elif op[0] == "compress":
+                    a = _u8(op[1])
+                    r = L.ref_stream_compress(h, _p(a) if len(a) else None, len(a), _p(out), cap, C.byref(w), C.byref(k))
+                else:
+                    a = _u8(op[1])
+                    r = L.ref_stream_compress_and_flush(h, _p(a) if len(a) else None, len(a), _p(out), cap, C.byref(w),
+                                                        C.byref(k), int(op[2]))
+                calls.append((r, out[: w.value].tobytes(), k.value))
+            return r0.value, calls
+        finally:
+            L.ref_stream_free(h)

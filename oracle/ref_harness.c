@@ -114,6 +114,24 @@ int ref_stream_reset_dictionary(void *h, unsigned char *out, size_t cap, size_t 
 
 void ref_stream_free(void *h) { free(h); }
 
+/* the same object below flush granularity: sink / full / poll / compress with the caller's output room */
+int ref_stream_sink(void *h, const unsigned char *in, size_t n, size_t *consumed) {
+    tamp_compressor_sink(&((RefStream *)h)->c, in, n, consumed);
+    return 0;
+}
+int ref_stream_full(void *h) { return tamp_compressor_full(&((RefStream *)h)->c) ? 1 : 0; }
+int ref_stream_poll(void *h, unsigned char *out, size_t cap, size_t *written) {
+    return tamp_compressor_poll(&((RefStream *)h)->c, out, cap, written);
+}
+int ref_stream_compress(void *h, const unsigned char *in, size_t n, unsigned char *out, size_t cap, size_t *written,
+                        size_t *consumed) {
+    return tamp_compressor_compress(&((RefStream *)h)->c, out, cap, written, in, n, consumed);
+}
+int ref_stream_compress_and_flush(void *h, const unsigned char *in, size_t n, unsigned char *out, size_t cap,
+                                  size_t *written, size_t *consumed, int write_token) {
+    return tamp_compressor_compress_and_flush(&((RefStream *)h)->c, out, cap, written, in, n, consumed, write_token != 0);
+}
+
 /* ---- resumable decoder object, one tamp_decompressor_decompress call at a time ---- */
 
 typedef struct {

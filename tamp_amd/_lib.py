@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtamp_amd.so")
 OK, OUTPUT_FULL, INPUT_EXHAUSTED = 0, 1, 2
 ERROR, EXCESS_BITS, INVALID_CONF, OOB = -1, -2, -3, -4
 NO_DEVICE, BAD_ARGUMENT = -20, -21
+OP_POLL, OP_COMPRESS, OP_FLUSH, OP_COMPRESS_AND_FLUSH = 1, 2, 3, 4  # include/tamp_amd.h TAMP_AMD_OP_*
 ALL_DEVICES = -1  # include/tamp_amd.h TAMP_AMD_ALL_DEVICES
 WINDOW_BITS_EXACT = 0x80  # include/tamp_amd.h: TAMP_AMD_WINDOW_BITS_EXACT
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -32,6 +33,9 @@ SYMBOLS = (
     "tamp_amd_decoder_state_size",
     "tamp_amd_decoder_state_init",
     "tamp_batch_decompress_resume",
+    "tamp_amd_encoder_state_size",
+    "tamp_amd_encoder_state_init",
+    "tamp_batch_compress_resume",
     "tamp_amd_compress",
     "tamp_amd_decompress",
     "tamp_amd_compress_segment",
@@ -42,6 +46,11 @@ SYMBOLS = (
     "tamp_amd_host_free",
     # include/tamp_compat.h: the reference's own symbol names
     "tamp_compressor_init",
+    "tamp_compressor_sink",
+    "tamp_compressor_full",
+    "tamp_compressor_poll",
+    "tamp_compressor_compress_cb",
+    "tamp_compressor_compress",
     "tamp_compressor_compress_and_flush_cb",
     "tamp_compressor_compress_and_flush",
     "tamp_compressor_flush",
@@ -118,6 +127,12 @@ def load() -> C.CDLL:
     lib.tamp_amd_decoder_state_init.restype = C.c_int8
     lib.tamp_batch_decompress_resume.argtypes = [vp, sz, u8, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, vp]
     lib.tamp_batch_decompress_resume.restype = i32
+    lib.tamp_amd_encoder_state_size.argtypes = [u8]
+    lib.tamp_amd_encoder_state_size.restype = sz
+    lib.tamp_amd_encoder_state_init.argtypes = [vp, C.POINTER(TampAmdConf), i32, u8]
+    lib.tamp_amd_encoder_state_init.restype = C.c_int8
+    lib.tamp_batch_compress_resume.argtypes = [vp, sz, u8, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, vp]
+    lib.tamp_batch_compress_resume.restype = i32
     lib.tamp_amd_compress.argtypes = [C.POINTER(TampAmdConf), vp, vp, sz, C.POINTER(sz), vp, sz, i32]
     lib.tamp_amd_compress.restype = C.c_int8
     lib.tamp_amd_decompress.argtypes = [vp, sz, vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz), i32]

