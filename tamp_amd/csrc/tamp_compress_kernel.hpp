@@ -96,7 +96,7 @@ struct CompressLds {
         obuf = o;
         o += align_up(obuf_words * 4, 16);
         ctl = o;
-        o += 64 + 64 * 4;  // control words + 64 sort bins
+        o += 64 + 64 * 4 + 16;  // control words + 64 sort bins + the 15 prefix codes as a byte table
         total = o;
     }
 };
@@ -116,6 +116,11 @@ constexpr uint64_t pack_nibbles(const uint8_t* v, int count) {
 }
 constexpr uint64_t kCodeLo = pack_bytes(kCodeTab, 0, 8), kCodeHi = pack_bytes(kCodeTab, 8, 7);
 constexpr uint64_t kNbitsPacked = pack_nibbles(kNbitsTab, 15);
+__device__ __forceinline__ uint64_t uni_u64(uint64_t x) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint32_t tok_code(uint32_t i) {
     return (uint32_t)((i < 8 ? kCodeLo >> (8 * i) : kCodeHi >> (8 * (i - 8))) & 0xFF);
 }
@@ -224,6 +229,10 @@ struct Walk {
 
     // write_to_bit_buffer (compressor.c:49-52) becomes "append an explicit piece to the token list"
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb) {
+        // (opaque to the optimiser: otherwise the constant (code, length) pairs of the rare tokens are hoisted out of
+        // the walk into VGPR pairs that live -- and spill -- for the whole kernel)
+        v = uni(v), nb = uni(nb);
+        asm volatile("" : "+s"(v), "+s"(nb));
         if (lane == 0) {
             stok[2 * ns] = v;
             stok[2 * ns + 1] = nb;
@@ -498,6 +507,8 @@ __global__ void __launch_bounds__(256, LAZY ? 4 : 6) tamp_compress_kernel(Compre
     uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
     volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
     uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 64);
+    // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
+    uint8_t* const codetab = smem + L.ctl + 64 + 256;
 
     const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
     uint32_t tid = tid_k;
@@ -507,12 +518,15 @@ __global__ void __launch_bounds__(256, LAZY ? 4 : 6) tamp_compress_kernel(Compre
     const bool ext = a.extended != 0;
     const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
     const uint32_t wbits = a.wbits, lbits = a.lbits;
+    if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier of the first stream
 
     for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
-        const uint8_t* const in = a.in + a.in_off[s];
-        const uint32_t n = a.in_len[s];
-        uint8_t* const gout = a.out + a.out_off[s];
-        const uint32_t cap = a.out_cap[s];
+        // per-stream table entries are wave-uniform but arrive through vector loads (the compiler cannot prove the
+        // tables invariant): pin them to scalar registers, or the two base pointers sit in VGPR pairs -- and spill
+        const uint8_t* const in = a.in + uni_u64(a.in_off[s]);
+        const uint32_t n = Walk::uni(a.in_len[s]);
+        uint8_t* const gout = a.out + uni_u64(a.out_off[s]);
+        const uint32_t cap = Walk::uni(a.out_cap[s]);
 
         uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + 4) : nullptr;
         uint32_t wp0 = 0;
@@ -1076,7 +1090,7 @@ __global__ void __launch_bounds__(256, LAZY ? 4 : 6) tamp_compress_kernel(Compre
                     nb = lbits + 1;
                     return (c >> lbits) == 0;
                 }
-                v = (tok_code(len - minp) << wbits) | idx;  // compressor.c:646-649
+                v = ((uint32_t)codetab[len - minp] << wbits) | idx;  // compressor.c:646-649
                 nb = tok_nbits(len - minp) + wbits;
                 return true;
             };
