@@ -46,7 +46,7 @@ typedef struct TampAmdConf {
     uint8_t use_custom_dictionary; /* `dictionary` argument holds 1<<window bytes shared by all streams */
     uint8_t extended;              /* library default of the reference is 1 (compressor.c:193-203) */
     uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
-    uint8_t lazy_matching;         /* compressor.c:576-619; about half the default mode's speed */
+    uint8_t lazy_matching;         /* compressor.c:576-619; a bit over half the default mode's speed */
     uint8_t reserved[2];
 } TampAmdConf;
 

@@ -183,6 +183,14 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy) {
             lds_cu / align_up(CompressLds(W, blk, packed, lazy).total, granule))
             blk = 1536;
     }
+    if (lazy && blk > 1024) {
+        // lazy matching keeps a second table per position: at W = 1024 only 1024-position epochs leave room for five
+        // workgroups per CU, which is also what its 96 VGPRs allow (measured: 15.5 -> 13.8 ms on config 2)
+        const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
+        if (lds_cu / align_up(CompressLds(W, 1024, packed, lazy).total, granule) >= 5 &&
+            lds_cu / align_up(CompressLds(W, blk, packed, lazy).total, granule) < 5)
+            blk = 1024;
+    }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions

@@ -481,7 +481,7 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
 // LAZY: lazy matching (compressor.c:576-619) compiled in; the default build carries none of its code.
 template <bool PACKED, bool LAZY>
-__global__ void __launch_bounds__(256, LAZY ? 4 : 6) tamp_compress_kernel(CompressArgs a) {
+__global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
     constexpr bool lazy = LAZY;
