@@ -950,3 +950,57 @@ def test_reference_named_compressor_below_flush_granularity(ta):
                                                                 bool(op[2]))
                 got = (st, bytes(out[: nw.value]), nc.value)
             assert got == (wst, wout, wcons), (name, k, op[0])
+
+
+def test_reference_named_object_mixes_token_level_and_segment_level_calls(ta, oracle):
+    """One TampCompressor object driven through both device paths: pieces below flush granularity (token-by-token
+    kernel, state in the object), then whole segments of several KiB (the batch kernel's segment mode, taken when the
+    object is between segments) -- the emitted bytes are one stream, identical to the oracle's for the same writes and
+    flush points, and the object's state stays coherent across the switch."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    sz = C.POINTER(C.c_size_t)
+    lib.tamp_compressor_init.restype = C.c_int8
+    lib.tamp_compressor_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tamp_compressor_compress.restype = C.c_int8
+    lib.tamp_compressor_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_char_p, C.c_size_t, sz]
+    lib.tamp_compressor_compress_and_flush.restype = C.c_int8
+    lib.tamp_compressor_compress_and_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_char_p, C.c_size_t, sz,
+                                                       C.c_bool]
+    text = wl.synth_text(1, 30000, first_index=5)[0].tobytes()
+    runs = wl.lcg_runs(1, 9000, first_index=8)[0].tobytes()
+    for lazy, dr in ((0, 0), (1, 1)):
+        tc = TampConf(window=10, literal=8, extended=1, dictionary_reset=dr, lazy_matching=lazy)
+        obj, window = (C.c_ubyte * 48)(), (C.c_ubyte * 1024)()
+        assert lib.tamp_compressor_init(obj, C.byref(tc), window) == 0
+        out = (C.c_ubyte * 70000)()
+        emitted = bytearray()
+
+        def call(fn, data, *extra):
+            nw, nc = C.c_size_t(0), C.c_size_t(0)
+            assert fn(obj, out, len(out), C.byref(nw), data, len(data), C.byref(nc), *extra) == 0
+            assert nc.value == len(data)
+            emitted.extend(bytes(out[: nw.value]))
+
+        pieces = [text[:37], text[37:700], runs[:5000], text[700:9000], runs[5000:9000] + text[9000:20000], text[20000:20011]]
+        call(lib.tamp_compressor_compress, pieces[0])                       # token level, ring left half full
+        call(lib.tamp_compressor_compress_and_flush, pieces[1], False)      # token level (ring not empty, < 2 KiB)
+        call(lib.tamp_compressor_compress_and_flush, pieces[2], True)       # segment level
+        call(lib.tamp_compressor_compress_and_flush, pieces[3], True)       # segment level
+        call(lib.tamp_compressor_compress, pieces[5])                       # token level again, 11 bytes stay in the ring
+        call(lib.tamp_compressor_compress_and_flush, pieces[4], False)      # token level: the ring is not empty
+        ops = [("write", pieces[0]), ("write", pieces[1]), ("flush", False), ("write", pieces[2]), ("flush", True),
+               ("write", pieces[3]), ("flush", True), ("write", pieces[5]), ("write", pieces[4]), ("flush", False)]
+        st, want = oracle.stream_script(ops, window=10, literal=8, extended=True, dictionary_reset=bool(dr),
+                                        lazy_matching=bool(lazy))
+        assert st == 0 and bytes(emitted) == want, (lazy, dr, len(emitted), len(want))
