@@ -96,12 +96,12 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
         if (lane < 4) reinterpret_cast<uint32_t*>(ring)[lane] = sw[3 + lane];
         __builtin_amdgcn_wave_barrier();
 
-        auto rd_in = [&](uint32_t k) -> uint32_t { return uni32(ring[(in_pos + k) & 15]); };  // read_input
-        auto put = [&](uint32_t bits, uint32_t n) {  // write_to_bit_buffer, compressor.c:49-52
+        auto rd_in = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t { return uni32(ring[(in_pos + k) & 15]); };  // read_input
+        auto put = [&](uint32_t bits, uint32_t n) __attribute__((always_inline)) {  // write_to_bit_buffer, compressor.c:49-52
             nb += n;
             bb |= bits << (32 - nb);
         };
-        auto partial_flush = [&]() -> int {  // compressor.c:65-75
+        auto partial_flush = [&]() __attribute__((always_inline)) -> int {  // compressor.c:65-75
             while (nb >= 8 && op < cap) {
                 if (lane == 0) out[op] = (uint8_t)(bb >> 24);
                 op++;
@@ -110,35 +110,58 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             }
             return nb >= 8 ? kOutputFull : kOk;
         };
-        auto last_byte = [&]() -> uint32_t { return uni32(win[(wp - 1) & mask]); };
-        auto win_write = [&](uint32_t b) {  // one byte at the cursor, wrapping
+        auto last_byte = [&]() __attribute__((always_inline)) -> uint32_t { return uni32(win[(wp - 1) & mask]); };
+        auto win_write = [&](uint32_t b) __attribute__((always_inline)) {  // one byte at the cursor, wrapping
             if (lane == 0) win[wp] = (uint8_t)b;
             wp = (wp + 1) & mask;
         };
-        auto put_exthuff = [&](uint32_t value, uint32_t trailing) {  // compressor.c:257-263
+        auto put_exthuff = [&](uint32_t value, uint32_t trailing) __attribute__((always_inline)) {  // compressor.c:257-263
             const uint32_t ci = value >> trailing;
             put((tok_code(ci) << trailing) | (value & ((1u << trailing) - 1)), (tok_nbits(ci) - 1) + trailing);
         };
 
         // find_best_match (compressor.c:113-172) for the ring from offset `o`, `R` bytes of it
-        auto find_best = [&](uint32_t o, uint32_t R, uint32_t& idx, uint32_t& len) {
+        auto find_best = [&](uint32_t o, uint32_t R, uint32_t& idx, uint32_t& len) __attribute__((always_inline)) {
             idx = 0, len = 0;
             if (R < minp) return;
             const uint32_t cmax = min(R, maxp);
-            uint32_t pat[4];
+            // the (up to 16) pattern bytes as four dwords (always indexed by constants: no scratch array)
+            uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                pat[k] = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) pat[k] |= (uint32_t)ring[(in_pos + o + 4 * k + j) & 15] << (8 * j);
+                pw0 |= (uint32_t)ring[(in_pos + o + k) & 15] << (8 * k);
+                pw1 |= (uint32_t)ring[(in_pos + o + 4 + k) & 15] << (8 * k);
+                pw2 |= (uint32_t)ring[(in_pos + o + 8 + k) & 15] << (8 * k);
+                pw3 |= (uint32_t)ring[(in_pos + o + 12 + k) & 15] << (8 * k);
             }
-            const uint32_t p01 = pat[0] & 0xFFFFu;
+            const uint32_t p01 = pw0 & 0xFFFFu;
             uint32_t key = 0;
-            for (uint32_t c = lane; c + 1 < W; c += kWave) {
-                if (((uint32_t)win[c] | ((uint32_t)win[c + 1] << 8)) != p01) continue;
-                uint32_t l = 2;
-                while (l < cmax && c + l < W && win[c + l] == ((pat[l >> 2] >> (8 * (l & 3))) & 0xFFu)) l++;
-                key = max(key, (l << 16) | (0xFFFFu - c));  // longest; ties -> lowest index
+            // 16 candidates per lane and pass: the two-byte filter is 16 independent LDS reads (one round trip); a
+            // survivor's length comes from four more, compared a dword at a time (reads may run up to 19 bytes past
+            // the window into the ring / slack behind it: cut off by the W - c cap)
+            for (uint32_t c0 = lane; c0 + 1 < W; c0 += 16 * kWave) {
+                uint32_t hits = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const uint32_t cc = c0 + k * kWave;
+                    const bool valid = cc + 1 < W;
+                    const uint32_t v = lds_u32_unaligned(win, valid ? cc : 0);
+                    hits |= (uint32_t)(valid && (v & 0xFFFFu) == p01) << k;
+                }
+                while (hits) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(hits);
+                    hits &= hits - 1;
+                    const uint32_t cc = c0 + k * kWave;
+                    const uint32_t x0 = lds_u32_unaligned(win, cc) ^ pw0, x1 = lds_u32_unaligned(win, cc + 4) ^ pw1;
+                    const uint32_t x2 = lds_u32_unaligned(win, cc + 8) ^ pw2, x3 = lds_u32_unaligned(win, cc + 12) ^ pw3;
+                    uint32_t l = 16;
+                    if (x3) l = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
+                    if (x2) l = 8 + ((uint32_t)__builtin_ctz(x2) >> 3);
+                    if (x1) l = 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+                    if (x0) l = (uint32_t)__builtin_ctz(x0) >> 3;
+                    l = min(l, min(cmax, W - cc));
+                    key = max(key, (l << 16) | (0xFFFFu - cc));  // longest; ties -> lowest index
+                }
             }
             key = wave_max_u32(key);
             if (key) {
@@ -147,7 +170,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             }
         };
         // find_extended_match (compressor.c:297-333)
-        auto find_ext = [&](uint32_t pos, uint32_t cnt, uint32_t& npos, uint32_t& ncnt) {
+        auto find_ext = [&](uint32_t pos, uint32_t cnt, uint32_t& npos, uint32_t& ncnt) __attribute__((always_inline)) {
             const uint32_t mp = min(cnt + in_size, maxp);
             const uint32_t nextb = rd_in(0);
             uint32_t key = 0;
@@ -165,7 +188,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             ncnt = key >> 16;
             npos = key ? 0xFFFFu - (key & 0xFFFFu) : pos;
         };
-        auto write_rle = [&](uint32_t count) {  // write_rle_token, compressor.c:342-359
+        auto write_rle = [&](uint32_t count) __attribute__((always_inline)) {  // write_rle_token, compressor.c:342-359
             const uint32_t sym = last_byte();
             put(tok_code(kSymRle), tok_nbits(kSymRle));
             put_exthuff(count - 2, 4);
@@ -174,7 +197,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             __builtin_amdgcn_wave_barrier();
             wp = (wp + ww) & mask;
         };
-        auto write_ext = [&]() -> int {  // write_extended_match_token, compressor.c:377-415
+        auto write_ext = [&]() __attribute__((always_inline)) -> int {  // write_extended_match_token, compressor.c:377-415
             if (cap - op < 6) return kOutputFull;
             const uint32_t count = extc, pos = extp;
             put(tok_code(kSymExt), tok_nbits(kSymExt));
@@ -200,14 +223,14 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             extc = 0;
             return kOk;
         };
-        auto consume = [&](uint32_t k) {
+        auto consume = [&](uint32_t k) __attribute__((always_inline)) {
             in_pos = (in_pos + k) & 15;
             in_size -= k;
         };
 
         constexpr int kPollContinue = 127;
         // poll_extended_handling, compressor.c:437-525
-        auto poll_ext = [&](uint32_t& midx, uint32_t& msize) -> int {
+        auto poll_ext = [&](uint32_t& midx, uint32_t& msize) __attribute__((always_inline)) -> int {
             if (extc) {
                 const uint32_t max_ext = minp + 11 + kExtExtraMax;
                 while (in_size > 0) {
@@ -258,7 +281,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             return kPollContinue;
         };
         // tamp_compressor_poll, compressor.c:532-660
-        auto poll = [&]() -> int {
+        auto poll = [&]() __attribute__((always_inline)) -> int {
             if (in_size == 0) return kOk;
             lwf = 0;
             int r = partial_flush();
@@ -317,7 +340,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             return kOk;
         };
         // tamp_compressor_sink + the loop of tamp_compressor_compress_cb, compressor.c:665-722
-        auto compress = [&]() -> int {
+        auto compress = [&]() __attribute__((always_inline)) -> int {
             while (in_left > 0 && op < cap) {
                 const uint32_t take = min(16u - in_size, in_left);
                 if (lane < take) ring[(in_pos + in_size + lane) & 15] = in[ip + lane];
@@ -331,7 +354,7 @@ __global__ void __launch_bounds__(256) tamp_compress_resume_kernel(EncodeResumeA
             return kOk;
         };
         // tamp_compressor_flush, compressor.c:728-810
-        auto flush = [&](bool write_token) -> int {
+        auto flush = [&](bool write_token) __attribute__((always_inline)) -> int {
             for (;;) {
                 int r = partial_flush();
                 if (r != kOk) return r;
