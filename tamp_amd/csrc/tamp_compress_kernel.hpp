@@ -285,22 +285,31 @@ struct Walk {
         ext_count = 0;
     }
 
-    // find_extended_match (compressor.c:297-333), candidates spread over the 64 lanes.
-    __device__ void ext_search(uint32_t R, uint32_t& npos, uint32_t& ncnt) {
+    // find_extended_match (compressor.c:297-333), candidates spread over the 64 lanes.  `avail` = input bytes the
+    // search may look at.  The reference searches once per 16-byte ring refill (cap = count + ring); every round
+    // keeps the lowest candidate among the longest and only candidates at or above it stay alive, so the rounds
+    // together select "longest common prefix with the input, capped by the window end and min+131; ties -> lowest
+    // index" among the candidates >= the first match -- which one search with the whole look-ahead finds directly.
+    __device__ void ext_search(uint32_t avail, uint32_t& npos, uint32_t& ncnt) {
         const uint32_t pos = ext_pos, cnt = ext_count;
-        const uint32_t maxp = min(cnt + R, minp + 11 + kExtExtraMax);
-        const uint32_t nextb = inb(0);
+        const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
+        // filter: the candidate's bytes cnt-3 .. cnt must equal the last three consumed bytes + the next input byte
+        // (the consumed bytes ARE the pattern: input [rd-cnt, rd) == window[pos, pos+cnt))
+        const uint32_t tail4 = uni(lds_u32_unaligned(ebuf, W + rd - 3));
+        const uint32_t nextb = tail4 >> 24;
+        const uint32_t wpv = wp();
         uint32_t key = 0;
-        // 16 candidates per lane and pass: the "next byte matches" filter is 16 independent LDS reads (one round
-        // trip), only the rare survivors are verified byte by byte
+        // 16 candidates per lane and pass: 16 independent LDS reads (one round trip); survivors are verified
         for (uint32_t c0 = pos + lane; c0 + cnt + 1 <= W; c0 += 16 * kWave) {
             uint32_t hits = 0;
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t c = c0 + k * kWave;
                 const bool valid = c + cnt + 1 <= W;
-                const uint32_t b = win_l(valid ? c + cnt : pos);
-                hits |= (uint32_t)(valid && b == nextb) << k;
+                const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
+                bool hit = lds_u32_unaligned(ebuf, wr + r) == tail4;
+                if (r > W - 4) hit = ebuf[wr + ((r + 3) & mask)] == nextb;  // the four bytes straddle the write cursor
+                hits |= (uint32_t)(valid && hit) << k;
             }
             while (hits) {
                 const uint32_t k = (uint32_t)__builtin_ctz(hits);
@@ -330,29 +339,29 @@ struct Walk {
     // One parse step = tamp_compressor_poll (compressor.c:532-660) with the ring = next R input bytes.
     // Returns kStepRebase *before mutating anything* when it needs a find_best_match result that the
     // current epoch cannot supply.
-    __device__ int step(uint32_t R) {
+    __device__ int step(uint32_t R, uint32_t left) {
         uint32_t idx = 0, len = 0;
         if (ext) {
-            if (ext_count) {  // compressor.c:439-468
+            if (ext_count) {  // compressor.c:439-468, all polls of the continuation at once (see ext_search)
                 lazy_valid = false;  // extended handling consumes input: any cached lazy match is stale (:563-568)
                 const uint32_t max_ext = minp + 11 + kExtExtraMax;
-                while (R > 0) {
+                while (left > 0) {
                     if (ext_pos + ext_count >= W || ext_count >= max_ext) {
                         emit_ext();
                         return kStepOk;
                     }
                     uint32_t npos, ncnt;
-                    const uint32_t reach = min(ext_count + R, max_ext);  // the search's own cap (compressor.c:308)
-                    ext_search(R, npos, ncnt);
+                    const uint32_t reach = min(ext_count + left, max_ext);
+                    ext_search(left, npos, ncnt);
                     if (ncnt > ext_count) {
                         uint32_t extra = ncnt - ext_count;
                         ext_pos = npos;
                         ext_count = ncnt;
                         rd += extra;
-                        R -= extra;
-                        // No candidate matched more than ncnt bytes of (pattern + ring).  Unless the cap stopped
-                        // it, the reference's next search (same bytes, a subset of the candidates) finds nothing
-                        // and emits the token; skip straight to that.
+                        left -= extra;
+                        // No candidate matched more than ncnt bytes of (pattern + input).  Unless the cap stopped
+                        // it (min+131 reached -> emitted at the top of the loop; input exhausted -> the flush emits
+                        // it), the reference's next search finds nothing and emits the token; skip straight to that.
                         if (ncnt == reach) continue;
                     }
                     emit_ext();
@@ -992,7 +1001,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const unsigned long long t0 = __builtin_readcyclecounter();
                             const uint32_t ec0 = wk.ext_count;
 #endif
-                            r = wk.step(leftp < kRing ? leftp : kRing);
+                            r = wk.step(leftp < kRing ? leftp : kRing, leftp);
 #ifdef TAMP_PROF
                             pt[11] += 1;
                             if (ec0) pt[5] += __builtin_readcyclecounter() - t0;  // time in extended-match continuation steps

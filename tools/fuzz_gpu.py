@@ -17,6 +17,22 @@ gens = [lambda n, L, k: wl.synth_text(n, L, first_index=k), lambda n, L, k: wl.l
         lambda n, L, k: np.random.default_rng(k).integers(0, 256, (n, L), dtype=np.uint8),
         lambda n, L, k: (np.random.default_rng(k).integers(0, 4, (n, L), dtype=np.uint8) * 37 + 65).astype(np.uint8),
         lambda n, L, k: np.repeat(np.random.default_rng(k).integers(0, 256, (n, (L + 6) // 7), dtype=np.uint8), 7, axis=1)[:, :L].copy()]
+def long_repeats(n, L, k):
+    # text-like bytes with long back-references (20-300 bytes copied from up to 1200 bytes back): long extended matches
+    r = np.random.default_rng(k)
+    rows = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        buf = bytearray(r.integers(97, 97 + int(r.integers(2, 20)), min(L, 64), dtype=np.uint8).tobytes())
+        while len(buf) < L:
+            if r.random() < 0.6 and len(buf) > 30:
+                d = int(r.integers(1, min(len(buf), 1200) + 1)); m = int(r.integers(14, 300))
+                for _ in range(m): buf.append(buf[-d])
+            else:
+                buf += r.integers(97, 123, int(r.integers(1, 12)), dtype=np.uint8).tobytes()
+        rows[i] = np.frombuffer(bytes(buf[:L]), dtype=np.uint8)
+    return rows
+gens.append(long_repeats)
+gens.append(long_repeats)
 while time.time() - t0 < budget:
     n = rng.choice([1, 3, 64, 200, 700])
     L = rng.choice([1, 2, 17, 100, 333, 1024, 3000, 4096, 9000])
