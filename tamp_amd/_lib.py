@@ -76,7 +76,8 @@ class TampAmdConf(C.Structure):
         ("extended", C.c_uint8),
         ("dictionary_reset", C.c_uint8),
         ("lazy_matching", C.c_uint8),
-        ("reserved", C.c_uint8 * 2),
+        ("input_hint", C.c_uint8),  # 0 auto, 1 plain, 2 run-aware build (include/tamp_amd.h TAMP_AMD_HINT_*)
+        ("reserved", C.c_uint8),
     ]
 
 

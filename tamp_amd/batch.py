@@ -44,9 +44,11 @@ class BatchResult:
         return [self.stream(i) for i in range(len(self.out_len))]
 
 
-def _conf(window, literal, extended, dictionary, dictionary_reset=False, lazy_matching=False) -> TampAmdConf:
+def _conf(window, literal, extended, dictionary, dictionary_reset=False, lazy_matching=False, run_aware=None) -> TampAmdConf:
+    # run_aware: None = TAMP_AMD_HINT_AUTO (host batches are sampled by the library), False = PLAIN, True = RUNS
+    hint = 0 if run_aware is None else (2 if run_aware else 1)
     return TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), int(bool(dictionary_reset)),
-                       int(bool(lazy_matching)))
+                       int(bool(lazy_matching)), hint)
 
 
 def _np_u8(x) -> np.ndarray:
@@ -82,16 +84,20 @@ def _slab_offsets(caps: np.ndarray):
 
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
                    dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
-                   max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False) -> BatchResult:
+                   max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False,
+                   run_aware=None) -> BatchResult:
     """Compress many independent streams in one launch.
 
     ``data`` is a list of bytes-likes (host), a flat numpy uint8 array + ``in_off``/``in_len`` (host), or a flat
     torch CUDA uint8 tensor + CUDA ``in_off`` (int64) / ``in_len`` (int32) tensors (device, zero-copy).
     Stream ``i``'s output equals ``tamp.compress(stream_i, window=..., literal=..., dictionary=..., extended=...)``
     of the reference.  ``status[i]`` holds the reference's ``tamp_res`` code for that stream.
+    ``run_aware`` picks the kernel build (same bytes either way): True for inputs with many runs of 8+ equal bytes
+    (source code, formatted text), False for plain text, None lets the library sample host batches (device batches
+    take the plain build).
     """
     lib = _lib.load()
-    conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching)
+    conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching, run_aware)
     if dictionary is not None and not _is_torch(dictionary) and len(dictionary) != (1 << window):
         raise ValueError("Dictionary-window size mismatch.")  # tamp/_c_compressor.pyx:43-46
     lib.tamp_amd_set_timing(1 if timing else 0)

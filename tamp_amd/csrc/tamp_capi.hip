@@ -169,7 +169,7 @@ struct SegmentSpec {  // streaming Compressor over the engine: how this piece of
     uint8_t flags;  // kSegResume | kSegSave | kSegFlushToken
 };
 
-uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy) {
+uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, bool runlist = false) {
     // positions matched per epoch: the whole stream when it is short, else 2048 -- or 1536 when the smaller LDS
     // footprint lets one more workgroup live on a CU (W = 1024: 25 KB instead of 30 KB, six instead of five; the extra
     // occupancy outweighs the third epoch of a 4 KiB stream).  Always a multiple of 64 (the walk chases 64 positions
@@ -179,22 +179,47 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy) {
     if (blk > 1536) {
         // (LDS is handed out in coarse granules: 26,960 B per workgroup measured as five per CU, 25,424 B as six)
         const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
-        if (lds_cu / align_up(CompressLds(W, 1536, packed, lazy).total, granule) >
-            lds_cu / align_up(CompressLds(W, blk, packed, lazy).total, granule))
+        if (lds_cu / align_up(CompressLds(W, 1536, packed, lazy, runlist).total, granule) >
+            lds_cu / align_up(CompressLds(W, blk, packed, lazy, runlist).total, granule))
             blk = 1536;
     }
     if (lazy && blk > 1024) {
         // lazy matching keeps a second table per position: at W = 1024 only 1024-position epochs leave room for five
         // workgroups per CU, which is also what its 96 VGPRs allow (measured: 15.5 -> 13.8 ms on config 2)
         const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
-        if (lds_cu / align_up(CompressLds(W, 1024, packed, lazy).total, granule) >= 5 &&
-            lds_cu / align_up(CompressLds(W, blk, packed, lazy).total, granule) < 5)
+        if (lds_cu / align_up(CompressLds(W, 1024, packed, lazy, runlist).total, granule) >= 5 &&
+            lds_cu / align_up(CompressLds(W, blk, packed, lazy, runlist).total, granule) < 5)
             blk = 1024;
     }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
     return blk;
+}
+
+// TAMP_AMD_HINT_AUTO for host-memory batches: look at up to 64 streams (first 4 KiB each).  The run-aware build pays
+// where runs of 8+ equal bytes are frequent but do not make up most of the data (there the RLE path owns nearly every
+// position anyway) and the streams are long enough to amortise its per-epoch search (measured: Python sources 16 runs
+// per KiB, 19 % of the bytes -> 1.37x; 256-byte telemetry padded with spaces 4 per KiB, 73 % -> 0.87x).
+uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams) {
+    uint64_t bytes = 0, runs = 0, in_runs = 0;
+    const size_t step = n_streams > 64 ? n_streams / 64 : 1;
+    for (size_t i = 0; i < n_streams; i += step) {
+        const uint8_t* p = in + in_off[i];
+        const uint32_t n = std::min<uint32_t>(in_len[i], 4096);
+        bytes += n;
+        for (uint32_t k = 0; k < n;) {
+            uint32_t e = k + 1;
+            while (e < n && p[e] == p[k]) e++;
+            if (e - k >= 8) runs++, in_runs += e - k;
+            k = e;
+        }
+    }
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_streams; i += step) total += in_len[i];
+    const uint64_t sampled = (n_streams + step - 1) / step;
+    const bool long_streams = total >= 1024 * sampled;
+    return (long_streams && bytes && runs * 1024 >= bytes && in_runs * 2 <= bytes) ? TAMP_AMD_HINT_RUNS : TAMP_AMD_HINT_PLAIN;
 }
 
 int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
@@ -231,8 +256,12 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     const uint32_t W = 1u << conf->window;
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
-    a.blk = pick_block(W, max_in_len, packed, a.lazy != 0);
-    const CompressLds L(W, a.blk, packed, a.lazy != 0);
+    // run-list build: long runs of one byte leave the bigram index; default parse only
+    bool runlist = conf->input_hint == TAMP_AMD_HINT_RUNS;
+    if (const char* e = getenv("TAMP_AMD_RUNS")) runlist = atoi(e) != 0;  // tuning / tests
+    runlist = runlist && !a.lazy;
+    a.blk = pick_block(W, max_in_len, packed, a.lazy != 0, runlist);
+    const CompressLds L(W, a.blk, packed, a.lazy != 0, runlist);
     if (L.total > ctx->lds_per_block) {
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
         return TAMP_AMD_BAD_ARGUMENT;
@@ -240,7 +269,8 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     const uint32_t threads = a.blk >= 1024 ? 256 : 64;
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
     auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true> : tamp_compress_kernel<false, true>)
-                         : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
+                  : runlist ? (packed ? tamp_compress_kernel<true, false, true> : tamp_compress_kernel<false, false, true>)
+                            : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
     timing_begin(st);
@@ -894,6 +924,9 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         for (size_t i = 0; i < n_streams; i++) maxlen = std::max(maxlen, in_len[i]);
         max_in_len = maxlen ? maxlen : 16;
     }
+    TampAmdConf conf_resolved = *conf;
+    if (conf_resolved.input_hint == TAMP_AMD_HINT_AUTO) conf_resolved.input_hint = sample_input_hint(in, in_off, in_len, n_streams);
+    conf = &conf_resolved;
     const HostBatch b = {in, in_off, in_len, out, out_off, out_cap, out_len, status, nullptr, n_streams};
     std::vector<HostChunk> chunks;
     // a chunk fills the device three times over (256 CUs x 6 workgroups = 1,536 streams at once); measured best for

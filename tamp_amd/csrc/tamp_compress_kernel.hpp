@@ -33,6 +33,8 @@ namespace tamp_amd {
 constexpr uint32_t kHashBits = 11;
 constexpr uint32_t kHashBuckets = 1u << kHashBits;
 constexpr uint32_t kRemBits = 16 - kHashBits;  // bigram bits not implied by the bucket number
+constexpr uint32_t kRunCap = 128;   // long runs listed per epoch (RUNS builds); further runs stay fully indexed
+constexpr uint32_t kLongRun = 8;    // a run of one byte this long is listed; its interior leaves the bigram index
 constexpr uint32_t kSlowCap = 256;             // explicit (non-derivable) token pieces per walk segment
 
 struct CompressArgs {
@@ -60,9 +62,9 @@ struct CompressArgs {
 
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
-    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, total;  // blen2/bidx2: lazy-matching probe results
+    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, rbits, total;  // blen2/bidx2: lazy-matching probe results
     uint32_t tokcap, obuf_words, jump, count, vstep;  // jump/count/vstep: byte offsets of the walk's tables inside `ent`
-    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false) {
+    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false, bool runlist = false) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
@@ -97,6 +99,12 @@ struct CompressLds {
         o += align_up(obuf_words * 4, 16);
         ctl = o;
         o += 64 + 64 * 4 + 16;  // control words + 64 sort bins + the 15 prefix codes as a byte table
+        // RUNS builds: the long runs of the epoch buffer (start | end << 16) and one bit per buffer position that
+        // is left out of the bigram index (the interior of a listed run)
+        runs = o;
+        if (runlist) o += kRunCap * 4;
+        rbits = o;
+        if (runlist) o += align_up((W + blk + 96) / 8, 16);
         total = o;
     }
 };
@@ -466,7 +474,7 @@ struct Walk {
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
 enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
 // ctl words
-enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8 };
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13 };
 
 #ifdef TAMP_PROF
 #define TAMP_PROF_MARK(i)                                     \
@@ -489,12 +497,14 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // PACKED: u32 index entries (position | rest of bigram | next byte | 3 bits of the one after); otherwise u16
 // positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
 // LAZY: lazy matching (compressor.c:576-619) compiled in; the default build carries none of its code.
-template <bool PACKED, bool LAZY>
+template <bool PACKED, bool LAZY, bool RUNS = false>
 __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a) {
+    static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t W = 1u << a.wbits, mask = W - 1;
+    const uint32_t a_wbits = a.wbits, a_blk = a.blk;
+    const uint32_t W = 1u << a_wbits, mask = W - 1;
     constexpr bool lazy = LAZY;
-    const CompressLds L(W, a.blk, PACKED, lazy);
+    const CompressLds L(W, a_blk, PACKED, lazy, RUNS);
     uint8_t* const ebuf = smem + L.ebuf;
     uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
     uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
@@ -518,16 +528,19 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 64);
     // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
     uint8_t* const codetab = smem + L.ctl + 64 + 256;
+    uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
+    uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
 
     const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
     uint32_t tid = tid_k;
     const int lane = tid & (kWave - 1);
     const uint32_t wave = tid >> 6;
-    const uint32_t minp = (uint32_t)min_pattern_size(a.wbits, a.lbits);
+    const uint32_t minp = (uint32_t)min_pattern_size((int)a_wbits, a.lbits);
     const bool ext = a.extended != 0;
     const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
-    const uint32_t wbits = a.wbits, lbits = a.lbits;
+    const uint32_t wbits = a_wbits, lbits = a.lbits;
     if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier of the first stream
+    if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier)
 
     for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
         // per-stream table entries are wave-uniform but arrive through vector loads (the compiler cannot prove the
@@ -570,7 +583,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         // Positions matched per epoch.  A token that breaks the speculation throws the rest of the block away, so
         // after such a break the next block is small (data with long runs / window-end truncations tends to break
         // again soon); a block that ends cleanly doubles it back up to the LDS capacity.
-        uint32_t cur_blk = a.blk;
+        uint32_t cur_blk = a_blk;
 #ifdef TAMP_PROF
         unsigned long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long pc = __builtin_readcyclecounter();
@@ -600,7 +613,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 for (uint32_t k = tid; k < kHashBuckets / 2; k += nt) cntw[k] = 0;
-                for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a.blk + 128; k += nt) blen[k] = 0x80;  // sentinels
+                for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a_blk + 128; k += nt) blen[k] = 0x80;  // sentinels
                 __syncthreads();
                 TAMP_PROF_MARK(0);
 #ifdef TAMP_PROF
@@ -613,6 +626,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
                     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
                     const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
+                    // RUNS builds: any run of 7+ bytes holds an aligned dword of four equal bytes; epochs without one
+                    // skip the run search
+                    if constexpr (RUNS) { if (d0 == (d0 & 0xFFu) * 0x01010101u) ctl[cQuad] = 1; }
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
                         if (c4 + j < NE) {
@@ -622,6 +638,53 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 __syncthreads();
+                uint32_t nruns = 0;  // listed runs of this epoch (RUNS builds)
+                if constexpr (RUNS) {
+                    if (Walk::uni(ctl[cQuad])) {
+                        // Long runs of one byte.  Every position inside such a run carries the same bigram: the bucket
+                        // of (x, x) grows with the run lengths and every query that starts with x x walks all of it.
+                        // The interior of a listed run [a, b) -- positions a+1 .. b-4: preceded by x and followed by
+                        // three more -- leaves the index (the counts above stay upper bounds; the scatter below skips
+                        // them); the match phase derives, per run, the few interior positions that can hold the best
+                        // match (see there).  Heads scan their own run; ends are capped a little past the indexed
+                        // range (any run remainder > 16 acts the same).
+                        for (uint32_t k = tid; k < (W + a_blk + 96) / 32; k += nt) rbits[k] = 0;
+                        if (tid == 0) ctl[cNruns] = 0;
+                        __syncthreads();
+                        if (tid == 0) ctl[cQuad] = 0;  // (everybody has read it: for the next epoch)
+                        const uint32_t lim = NE + 16;
+                        for (uint32_t c = tid; c < NE; c += nt) {
+                            const uint32_t b4 = lds_u32_unaligned(ebuf, c), x = b4 & 0xFFu;
+                            if (b4 == x * 0x01010101u && (c == 0 || ebuf[c - 1] != x)) {
+                                uint32_t e = c + 4;
+                                while ((e & 3u) && e < lim && ebuf[e] == x) e++;
+                                if (!(e & 3u)) {
+                                    while (e + 8 <= lim) {  // aligned dword pairs
+                                        const uint32_t* wv = reinterpret_cast<const uint32_t*>(ebuf + e);
+                                        const uint32_t v0 = wv[0], v1 = wv[1];
+                                        if (v0 != b4 || v1 != b4) break;
+                                        e += 8;
+                                    }
+                                    while (e < lim && ebuf[e] == x) e++;
+                                }
+                                if (e - c >= kLongRun) {
+                                    const uint32_t slot = atomicAdd(const_cast<uint32_t*>(&ctl[cNruns]), 1u);
+                                    if (slot < kRunCap) {
+                                        runs[slot] = c | (e << 16);
+                                        for (uint32_t k = c + 1; k <= e - 4;) {  // bits [c+1, e-4]
+                                            const uint32_t hiw = min(e - 4, k | 31u);
+                                            const uint32_t m = (0xFFFFFFFFu << (k & 31u)) & (0xFFFFFFFFu >> (31u - (hiw & 31u)));
+                                            atomicOr(&rbits[k >> 5], m);
+                                            k = hiw + 1;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        nruns = min(Walk::uni(ctl[cNruns]), kRunCap);
+                    }
+                }
                 {  // exclusive scan of the 2048 u16 counters in place
                     const uint32_t per = kHashBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
                     uint32_t sum = 0;
@@ -659,11 +722,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         const uint32_t mx = mix16(b4 & 0xFFFFu);
                         h = mx >> kRemBits;
                         const uint32_t sh = (h & 1) * 16;
-                        const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
-                        if (PACKED)
-                            ent[(old >> sh) & 0xFFFFu] = c | entry_payload(b4, mx);
-                        else
-                            ent16[(old >> sh) & 0xFFFFu] = (uint16_t)c;
+                        bool keep = true;
+                        if constexpr (RUNS) { if (nruns) keep = !((rbits[c >> 5] >> (c & 31u)) & 1u); }
+                        if (keep) {
+                            const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
+                            if (PACKED)
+                                ent[(old >> sh) & 0xFFFFu] = c | entry_payload(b4, mx);
+                            else
+                                ent16[(old >> sh) & 0xFFFFu] = (uint16_t)c;
+                        }
                     }
                     __syncthreads();
                     if (c < NE && c >= W) bidx[c - W] = cnt16[h];
@@ -878,12 +945,96 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
                     TAMP_FINE(f2);
                 }
+                if constexpr (RUNS) {
+                    // Second pass, only in epochs with listed runs: interior positions of those runs are not in the
+                    // index.  They only matter to a pattern that starts with the run's byte twice.  Let rq = the
+                    // pattern's own leading run and, for a run [a, b), rc = b - c the run remainder at candidate c.
+                    // rc > rq: the match is exactly rq bytes, for all such c alike; rc < rq: exactly rc bytes, shrinking
+                    // as c grows; rc == rq: the one candidate that can go past the run.  With "longest, then lowest
+                    // window index" and the limit W - index, the best interior candidate of the run inside the window
+                    // is one of: the first one, the one at window index 0, b - rq, b - rq + 1.  Those (at most) four
+                    // are compared like any index entry and merged into the result of the first pass (each thread
+                    // revisits its own queries).  Interior positions within 15 bytes of the newest window byte run into
+                    // the oldest ones like their indexed neighbours (prefix_len_wrapped16).
+                    if (nruns) {
+                        for (uint32_t j = tid; j < nq; j += nt) {
+                            const uint32_t q = sorted[j];
+                            const uint32_t b01 = lds_u32_unaligned(ebuf, W + q);
+                            const uint32_t x = b01 & 0xFFu;
+                            if (((b01 >> 8) & 0xFFu) != x) continue;
+                            const uint32_t leftq = n - (e_p0 + q);
+                            const uint32_t R = leftq < kRing ? leftq : kRing;
+                            if (R < minp) continue;
+                            uint32_t P[4];
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) P[jj] = lds_u32_unaligned(ebuf, W + q + 4 * jj);
+                            const uint32_t rep = x * 0x01010101u;
+                            uint32_t rq = 16;
+#pragma unroll
+                            for (int jj = 3; jj >= 0; jj--) {
+                                const uint32_t xx = P[jj] ^ rep;
+                                if (xx) rq = 4u * (uint32_t)jj + ((uint32_t)__builtin_ctz(xx) >> 3);
+                            }
+                            if (ext && ebuf[W + q - 1] == x && (min(rq, 7u) >= 7u || rq >= R)) continue;  // the RLE path owns it (no scan above either)
+                            const uint32_t cap_len = R < maxp ? R : maxp;
+                            const uint32_t sv = blen[q];
+                            uint32_t key = (sv & 0x1Fu) ? (((sv & 0x1Fu) << 16) | (W - (uint32_t)bidx[q])) : 0u;
+                            const uint32_t key0 = key;
+                            {   // wrap zone: every position t = 2..15 bytes before the window's end whose bigram is (x, x)
+                                uint32_t eq = 0;
+#pragma unroll
+                                for (uint32_t jj = 0; jj < 4; jj++) {
+                                    const uint32_t y = lds_u32_unaligned(ebuf, q + W - 16 + 4 * jj) ^ rep;
+                                    uint32_t z = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+                                    z = ~(z | y | 0x7F7F7F7Fu);  // 0x80 in every byte of y that is zero
+                                    eq |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * jj);
+                                }
+                                const uint32_t bg = eq & (eq >> 1);  // bit k: buffer positions q+W-16+k and +k+1 hold x
+                                uint32_t wrapmask = (__builtin_bitreverse32(bg) >> 15) & 0xFFFCu;  // t = 16 - k
+                                while (wrapmask) {
+                                    const uint32_t t = (uint32_t)__builtin_ctz(wrapmask);
+                                    wrapmask &= wrapmask - 1;
+                                    const uint32_t c = q + W - t;
+                                    if (!((rbits[c >> 5] >> (c & 31u)) & 1u)) continue;  // indexed: the first pass had it
+                                    const uint32_t i = (e_wp + c) & mask;
+                                    if (i == mask) continue;
+                                    const uint32_t len = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_len, W - i));
+                                    const uint32_t k = (len << 16) | (W - i);
+                                    if (len >= 2 && k > key) key = k;
+                                }
+                            }
+                            const uint32_t cz = q + ((0u - e_wp - q) & mask);  // the window position with index 0
+#pragma unroll 1
+                            for (uint32_t k = 0; k < nruns; k++) {
+                                const uint32_t rv = runs[k], ra = rv & 0xFFFFu, rb = rv >> 16;
+                                if (ebuf[ra] != x) continue;
+                                const uint32_t lo = max(ra + 1, q), hi = min(rb - 4, q + W - 16);
+                                if (lo > hi) continue;
+                                const uint32_t cs = rb - rq;
+#pragma unroll 1
+                                for (uint32_t m = 0; m < 4; m++) {
+                                    const uint32_t c = m == 0 ? lo : (m == 1 ? cz : cs + (m - 2));
+                                    if (c < lo || c > hi || (m && c == lo)) continue;
+                                    const uint32_t lim_i = W - ((c + e_wp) & mask);
+                                    const uint32_t len = prefix_len16(ebuf, c, P);
+                                    key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
+                                }
+                            }
+                            if (key != key0) {
+                                const uint32_t len = key >> 16;
+                                const bool slow = (sv & 0x80u) || (ext && len > minp + 11);
+                                blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
+                                bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
+                            }
+                        }
+                    }
+                }
                 __syncthreads();
                 TAMP_FINE(f3);
 #ifdef TAMP_PROF
                 pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[10] += niter;
 #endif
-                for (uint32_t k = 4 + tid; k < 4 + a.blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
+                for (uint32_t k = 4 + tid; k < 4 + a_blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
                 // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
                 // the chain of plain steps starting there leaves the block (or the "slow" position it stops at) and how
@@ -894,7 +1045,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 // be written -- a literal, and hands B[p] to the next position.  That is a deterministic transition on
                 // the 2 x nvalid states v = 2p + state: it is tabulated here and chased with the same pointer doubling.
                 if constexpr (LAZY) {
-                    for (uint32_t v = tid; v < nv + 128 && v < 2 * a.blk + 128; v += nt) {
+                    for (uint32_t v = tid; v < nv + 128 && v < 2 * a_blk + 128; v += nt) {
                         uint32_t out = 0x80u;  // stop: the state machine takes this step
                         const uint32_t pp = v >> 1, s1 = v & 1u;
                         if (v < nv && pp + 1 < nvalid && !(s1 && pp == 0)) {
@@ -1047,8 +1198,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t shift = wk.wr;
                     // broke inside the block (lag) -> quarter it; ran off its end -> double it
                     const bool broke = wk.wr + pending != wk.rd;  // bytes were consumed that will never be written
-                    uint32_t nb2 = broke ? max(cur_blk >> 2, 256u) : min(cur_blk << 1, a.blk);
-                    nb2 = min(nb2, a.blk);
+                    uint32_t nb2 = broke ? max(cur_blk >> 2, 256u) : min(cur_blk << 1, a_blk);
+                    nb2 = min(nb2, a_blk);
                     if (lane == 0) ctl[cBlk] = nb2;
                     wk.wp_e = wk.wp();
                     w_p0 += wk.rd - pending;

@@ -174,6 +174,57 @@ def test_differential_vs_oracle(ta, oracle):
             assert got == want, (it, j, w, lit, ext, cap, got[0], want[0], len(got[1]), len(want[1]))
 
 
+def _runny_text(rng, n):
+    """Indented / ruled / padded text: runs of 8-80 equal bytes between short words (what the run-aware build lists)."""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.randrange(6)
+        if k == 0:
+            out += b"\n" + b" " * rng.choice([4, 8, 8, 12, 16, 20, 40])
+        elif k == 1:
+            out += bytes([rng.choice(b"-=* #")]) * rng.randrange(7, 80)
+        elif k == 2:
+            out += b" " * rng.randrange(1, 12)
+        else:
+            out += bytes(rng.choice(b"abcdefgh(): ") for _ in range(rng.randrange(1, 9)))
+    return bytes(out[:n])
+
+
+def test_run_aware_build_matches_oracle(ta, oracle):
+    """TAMP_AMD_HINT_RUNS (long runs listed once instead of indexed byte by byte) produces the same bytes as the
+    reference on run-heavy and ordinary inputs, every window size, both formats; AUTO on host batches likewise."""
+    from tamp_amd import workloads as wl
+
+    rng = random.Random(11)
+    for it in range(60):
+        w = rng.choice([8, 9, 10, 10, 10, 11, 12, 13, 15])
+        lit = rng.choice([8, 8, 8, 7])
+        ext = rng.random() < 0.7
+        d = None
+        if rng.random() < 0.3:
+            d = (_runny_text(rng, 1 << w) if rng.random() < 0.5 else _rand_inputs(rng, wl, 1 << w) + bytes(1 << w))[: 1 << w]
+        datas = []
+        for _ in range(rng.randrange(1, 16)):
+            n = rng.choice([0, 1, 7, 8, 9, 17, 100, 256, 1000, 4096, 4096, rng.randrange(1, 12000)])
+            x = _runny_text(rng, n) if rng.random() < 0.6 else _rand_inputs(rng, wl, n)
+            if lit < 8:
+                x = bytes(b & 0x7F for b in x)
+            datas.append(x)
+        for mode in (True, None):
+            res = ta.compress_batch(datas, window=w, literal=lit, extended=ext, dictionary=d, run_aware=mode)
+            for j, x in enumerate(datas):
+                st, want = oracle.compress(x, window=w, literal=lit, extended=ext, dictionary=d)
+                assert int(res.status[j]) == st, (it, j, w, lit, ext, mode, len(x))
+                assert res.stream(j) == want, (it, j, w, lit, ext, mode, len(x))
+    # a batch the host sampler routes to the run-aware build (source-code-like), at config-2 stream size
+    rows = np.frombuffer(b"".join(_runny_text(rng, 4096) for _ in range(512)), dtype=np.uint8).reshape(512, 4096)
+    off, ln = wl.csr_for_fixed(512, 4096)
+    res = ta.compress_batch(rows.reshape(-1), off, ln, max_in_len=4096)
+    want = oracle.compress_batch(rows.reshape(-1), off, ln, threads=8)
+    for j in range(512):
+        assert res.stream(j) == want.stream(j), j
+
+
 def test_excess_bits_and_invalid_conf(ta, oracle):
     from tamp_amd import workloads as wl
 

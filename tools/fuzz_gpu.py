@@ -49,7 +49,7 @@ while time.time() - t0 < budget:
     kw = dict(window=window, literal=literal, extended=ext, lazy_matching=lazy, dictionary=d)
     flat = np.ascontiguousarray(rows).reshape(-1)
     off, ln = wl.csr_for_fixed(n, L)
-    got = tamp_amd.compress_batch(flat, off, ln, max_in_len=L, **kw)
+    got = tamp_amd.compress_batch(flat, off, ln, max_in_len=L, run_aware=rng.choice([None, False, True, True]), **kw)
     want = o.compress_batch(flat, off, ln, threads=16, **{('lazy' if k == 'lazy_matching' else k): v for k, v in kw.items()})
     comp = []
     for i in range(n):
