@@ -197,6 +197,7 @@ struct Walk {
     uint32_t wr, rd;  // bytes written / consumed since epoch start
     uint32_t nvalid;
     uint32_t rle_count, ext_count, ext_pos;
+    bool ext_resolved;
     uint32_t ntok, ns;
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
@@ -337,16 +338,20 @@ struct Walk {
 
     enum { kStepOk = 0, kStepRebase = 1, kStepExcess = 2 };
 
-    __device__ __forceinline__ bool best(uint32_t& idx, uint32_t& len) const {
+    template <bool RB>
+    __device__ __forceinline__ bool best(uint32_t& idx, uint32_t& len) {
         if (wr != rd || rd >= nvalid) return false;
-        len = uni(blen[rd]) & 0x1Fu;
+        const uint32_t sv = uni(blen[rd]);
+        len = sv & 0x1Fu;
         idx = uni(bidx[rd]);
+        if constexpr (RB) ext_resolved = (sv & 0x40u) != 0;  // idx is the final index of the extended match that starts here
         return true;
     }
 
     // One parse step = tamp_compressor_poll (compressor.c:532-660) with the ring = next R input bytes.
     // Returns kStepRebase *before mutating anything* when it needs a find_best_match result that the
     // current epoch cannot supply.
+    template <bool RB>
     __device__ int step(uint32_t R, uint32_t left) {
         uint32_t idx = 0, len = 0;
         if (ext) {
@@ -401,7 +406,7 @@ struct Walk {
             if (total >= 2) {
                 bool use_pattern = false;
                 if (total == avail && total <= 6) {
-                    if (!best(idx, len)) return kStepRebase;
+                    if (!best<RB>(idx, len)) return kStepRebase;
                     if (len > total)
                         use_pattern = true;
                     else
@@ -427,7 +432,7 @@ struct Walk {
             const bool from_cache = lazy_valid;
             if (!from_cache) {
                 cidx = idx, clen = len;
-                if (clen == 0 && !best(cidx, clen)) return kStepRebase;
+                if (clen == 0 && !best<RB>(cidx, clen)) return kStepRebase;
             }
             bool defer = false;
             uint32_t nidx = 0, nlen = 0;
@@ -445,7 +450,7 @@ struct Walk {
                 lazy_valid = true, lazy_idx = nidx, lazy_len = nlen;
                 len = 0;  // literal now, the better match at the next position
             }
-        } else if (len == 0 && !best(idx, len)) {
+        } else if (len == 0 && !best<RB>(idx, len)) {
             return kStepRebase;
         }
 
@@ -456,6 +461,29 @@ struct Walk {
             len = 1;
         } else {
             if (ext && len > minp + 11) {  // compressor.c:636-644
+                if (RB && ext_resolved) {
+                    // the match phase saw no other candidate that could carry the continuation: count the common
+                    // prefix of that window position and the input (four bytes per lane) and emit -- unless the match
+                    // reaches the newest window byte, where the ring goes on with the oldest one (search instead)
+                    ext_resolved = false;
+                    const uint32_t off = (idx - wp()) & mask, t0 = W - off;
+                    const uint32_t xx = lds_u32_unaligned(ebuf, wr + off + 4u * (uint32_t)lane) ^ lds_u32_unaligned(ebuf, W + rd + 4u * (uint32_t)lane);
+                    const uint64_t bal = __ballot(xx != 0);
+                    uint32_t lcp = 256;
+                    if (bal) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(bal);
+                        const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)xx, (int)f);
+                        lcp = 4u * f + ((uint32_t)__builtin_ctz(xf) >> 3);
+                    }
+                    const uint32_t cnt = min(min(lcp, W - idx), min(minp + 11 + kExtExtraMax, left));
+                    if (cnt < t0 && cnt >= len) {
+                        ext_pos = idx;
+                        ext_count = cnt;
+                        rd += cnt;
+                        emit_ext();
+                        return kStepOk;
+                    }
+                }
                 ext_count = len;
                 ext_pos = idx;
                 rd += len;
@@ -571,7 +599,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
         wk.wp_e = wp0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
-        wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+        wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
@@ -786,6 +814,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t leftq = n - (e_p0 + q);
                     const uint32_t R = leftq < kRing ? leftq : kRing;
                     uint32_t key = 0;
+                    uint32_t wrapbest = 0, n16 = 0;  // RUNS builds: best wrap-zone hit, number of 16-byte hits of the scan
+                    bool sole_ext = false;
                     // lazy matching: the same pattern also probes the window as it was one position earlier (window
                     // start q-1, one byte less look-ahead): compressor.c:585-596 restated per position
                     uint32_t keyB = 0, wrapmaskB = 0, cap_lenB = 0;
@@ -843,6 +873,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     } else {
                                         uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
                                         if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                                        if constexpr (RUNS) n16 += len >> 4;
                                         // key = length << 16 | (W - index): longest, then lowest index.  W - i is also
                                         // the limit "may not run past index W-1"; a clipped length of 1 (index W-1)
                                         // yields a key below every real match and is read as "no match" later.
@@ -902,9 +933,25 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const uint32_t c = q + W - t;
                             const uint32_t i = (e_wp + c) & mask;
                             if (i == mask) continue;
-                            const uint32_t len = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_len, W - i));
+                            const uint32_t lw = prefix_len_wrapped16(ebuf, c, t, W, P);
+                            if constexpr (RUNS) wrapbest = max(wrapbest, lw);
+                            const uint32_t len = min(lw, min(cap_len, W - i));
                             const uint32_t k = (len << 16) | (W - i);
                             if (len >= 2 && k > key) key = k;
+                        }
+                        if constexpr (RUNS) {
+                            // Extended matches (compressor.c:437-468, 636-644): a first match longer than min+11 starts
+                            // a continuation that ends at "the candidate at or above the first match's index with the
+                            // longest common prefix with the input, capped by the window end and min+131"
+                            // (Walk::ext_search).  Every such candidate shares the first match's bytes.  A first match
+                            // shorter than the 16-byte ring cannot grow at all (no candidate got past it inside the
+                            // ring); a 16-byte one that was the only 16-byte hit of the scan has no rival.  Both are
+                            // flagged (bit 6 of blen): the walk then just counts the common prefix at that index instead
+                            // of searching the window.  Left to the search: several 16-byte hits, hits that run past the
+                            // newest window byte, patterns that start inside a listed run.
+                            const uint32_t len0 = key >> 16;
+                            if (ext && len0 > minp + 11 && !(nruns && P[0] == rep) && (len0 < 16 || (n16 == 1 && wrapbest < 16)))
+                                sole_ext = true;
                         }
                     }
                     if (cap_lenB) {
@@ -941,7 +988,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
                         slow = (prev == b0 && (b1 == b0 || R == 1)) || (!lazy && len > minp + 11);
                     }
-                    blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
+                    blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u) | (RUNS && sole_ext ? 0x40u : 0u));
                     bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
                     TAMP_FINE(f2);
                 }
@@ -980,6 +1027,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const uint32_t sv = blen[q];
                             uint32_t key = (sv & 0x1Fu) ? (((sv & 0x1Fu) << 16) | (W - (uint32_t)bidx[q])) : 0u;
                             const uint32_t key0 = key;
+                            bool hit16 = false;  // a 16-byte hit the first pass did not see: a rival for an extended match
                             {   // wrap zone: every position t = 2..15 bytes before the window's end whose bigram is (x, x)
                                 uint32_t eq = 0;
 #pragma unroll
@@ -998,7 +1046,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     if (!((rbits[c >> 5] >> (c & 31u)) & 1u)) continue;  // indexed: the first pass had it
                                     const uint32_t i = (e_wp + c) & mask;
                                     if (i == mask) continue;
-                                    const uint32_t len = min(prefix_len_wrapped16(ebuf, c, t, W, P), min(cap_len, W - i));
+                                    // (in ring terms such a position is not "four equal bytes": past the newest byte
+                                    // come the oldest ones, so it can match anything -- including all 16 bytes)
+                                    const uint32_t lw = prefix_len_wrapped16(ebuf, c, t, W, P);
+                                    hit16 = hit16 || lw >= 16;
+                                    const uint32_t len = min(lw, min(cap_len, W - i));
                                     const uint32_t k = (len << 16) | (W - i);
                                     if (len >= 2 && k > key) key = k;
                                 }
@@ -1020,7 +1072,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
                                 }
                             }
-                            if (key != key0) {
+                            if (key != key0 || (hit16 && (sv & 0x40u))) {
                                 const uint32_t len = key >> 16;
                                 const bool slow = (sv & 0x80u) || (ext && len > minp + 11);
                                 blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u));
@@ -1152,7 +1204,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const unsigned long long t0 = __builtin_readcyclecounter();
                             const uint32_t ec0 = wk.ext_count;
 #endif
-                            r = wk.step(leftp < kRing ? leftp : kRing, leftp);
+                            r = wk.template step<RUNS>(leftp < kRing ? leftp : kRing, leftp);
 #ifdef TAMP_PROF
                             pt[11] += 1;
                             if (ec0) pt[5] += __builtin_readcyclecounter() - t0;  // time in extended-match continuation steps

@@ -56,6 +56,12 @@ while time.time() - t0 < budget:
         a, b = got.stream(i), want.stream(i)
         if int(got.status[i]) != int(want.status[i]) or a != b:
             print('COMPRESS MISMATCH', kw if d is None else {**kw, 'dictionary': 'custom'}, n, L, i, int(got.status[i]), int(want.status[i]), len(a), len(b))
+            outdir = os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'gpurun_out')
+            os.makedirs(outdir, exist_ok=True)
+            np.save(os.path.join(outdir, 'fuzz_fail_input.npy'), np.asarray(rows[i]))
+            open(os.path.join(outdir, 'fuzz_fail_got.bin'), 'wb').write(a)
+            open(os.path.join(outdir, 'fuzz_fail_want.bin'), 'wb').write(b)
+            if d is not None: open(os.path.join(outdir, 'fuzz_fail_dict.bin'), 'wb').write(d)
             sys.exit(1)
         comp.append(b)
     cap = rng.choice([L + 8, L, max(1, L // 2), L + 300])
