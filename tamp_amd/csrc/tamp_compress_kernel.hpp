@@ -198,6 +198,7 @@ struct Walk {
     uint32_t nvalid;
     uint32_t rle_count, ext_count, ext_pos;
     bool ext_resolved;
+    bool last_ext_direct = false;  // (instrumented builds)
     uint32_t ntok, ns;
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
@@ -477,6 +478,7 @@ struct Walk {
                     }
                     const uint32_t cnt = min(min(lcp, W - idx), min(minp + 11 + kExtExtraMax, left));
                     if (cnt < t0 && cnt >= len) {
+                        last_ext_direct = true;
                         ext_pos = idx;
                         ext_count = cnt;
                         rd += cnt;
@@ -1209,6 +1211,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             pt[11] += 1;
                             if (ec0) pt[5] += __builtin_readcyclecounter() - t0;  // time in extended-match continuation steps
                             else pt[9] += __builtin_readcyclecounter() - t0;      // other slow steps
+                            if (ec0) pt[14] += 1;                         // extended matches that went through the search
+                            if (!ec0 && wk.ntok >= 3 && wk.ns >= 3 && wk.last_ext_direct) pt[15] += 1;  // ... settled without one
+                            wk.last_ext_direct = false;
 #endif
                         }
                         if (r == Walk::kStepRebase) {

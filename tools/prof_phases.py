@@ -37,6 +37,7 @@ for ext in (1, 0):
         lib.tamp_amd_prof_read(buf)
     v = np.array(list(buf), dtype=np.float64) / n
     print(f"   epochs/stream={v[12]:.1f} positions matched/stream={v[13]:.0f}")
+    print(f"   extended matches/stream: searched={v[14]:.1f} settled without a search={v[15]:.1f}")
     print(f"   walk detail: slow steps/stream={v[11]:.1f} cycles in ext-continuation steps={v[5]:.0f} other slow steps={v[9]:.0f}")
     print(f"   fine: setup={v[6]:.0f} loop={v[7]:.0f} special+epilog={v[8]:.0f} barrierwait={v[9]:.0f} iters(thread0)={v[10]:.0f}")
     print(f"ext={ext} kernel_ms={r.kernel_ms:.2f} cycles/stream: load+zero={v[0]:.0f} index={v[1]:.0f} match={v[2]:.0f} walk={v[3]:.0f} emit={v[4]:.0f}  (s_memtime ticks @100MHz?)")
