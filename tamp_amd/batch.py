@@ -82,6 +82,16 @@ def _slab_offsets(caps: np.ndarray):
     return offs, int(caps.astype(np.uint64).sum())
 
 
+def input_hint(sample) -> bool:
+    """The library's AUTO sampling on a host-side sample (list of bytes-likes): True when the run-aware build of the
+    compress kernel should parse data like this (pass it as ``run_aware=`` for device batches)."""
+    lib = _lib.load()
+    flat, off, ln = pack_streams([bytes(x) for x in sample])
+    if not len(ln):
+        return False
+    return lib.tamp_amd_input_hint(flat.ctypes.data, off.ctypes.data, ln.ctypes.data, len(ln)) == 2
+
+
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
                    dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
                    max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False,

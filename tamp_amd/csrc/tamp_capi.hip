@@ -830,6 +830,11 @@ void tamp_window_copy(unsigned char* window, uint16_t* window_pos, uint16_t wind
     *window_pos = p;
 }
 
+uint8_t tamp_amd_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams) {
+    if (!in || !in_off || !in_len || !n_streams) return TAMP_AMD_HINT_PLAIN;
+    return sample_input_hint(in, in_off, in_len, n_streams);
+}
+
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset) {
     return 1 + (dictionary_reset ? 1 : 0) + (n * ((size_t)literal + 1) + 7) / 8;
 }
