@@ -386,18 +386,22 @@ struct Walk {
             // RLE accumulation, compressor.c:470-525
             const uint32_t last = win((wp() - 1) & mask);
             uint32_t avail = 0;
-            {   // leading ring bytes equal to `last`: 16 bytes compared at once (first differing byte via ctz)
-                const uint32_t rep = last * 0x01010101u;
-                uint32_t run = 16;
-#pragma unroll
-                for (int j = 3; j >= 0; j--) {
-                    const uint32_t x = uni(lds_u32_unaligned(ebuf, W + rd + 4 * j)) ^ rep;
-                    if (x) run = 4 * j + ((uint32_t)__builtin_ctz(x) >> 3);
+            {   // Leading input bytes equal to `last`, the whole run at once (four bytes per lane, one ballot).  The
+                // reference takes a run one 16-byte ring at a time and carries `rle_count` from poll to poll; nothing
+                // else happens between those polls, so the count it arrives at is "run length, capped at 241 and at
+                // the end of the input" -- the run's bytes all lie inside the loaded look-ahead (16 + 256 bytes).
+                const uint32_t x = lds_u32_unaligned(ebuf, W + rd + 4u * (uint32_t)lane) ^ (last * 0x01010101u);
+                const uint64_t bal = __ballot(x != 0);
+                uint32_t run = 256;
+                if (bal) {
+                    const uint32_t f = (uint32_t)__builtin_ctzll(bal);
+                    const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)f);
+                    run = 4u * f + ((uint32_t)__builtin_ctz(xf) >> 3);
                 }
-                avail = min(min(run, R), kRleMax - rle_count);
+                avail = min(min(uni(run), left), kRleMax - rle_count);
             }
             const uint32_t total = rle_count + avail;
-            const bool ended = (avail < R) || (total >= kRleMax);
+            const bool ended = (avail < left) || (total >= kRleMax);
             if (!ended && total > 0) {
                 rle_count = total;
                 rd += avail;
