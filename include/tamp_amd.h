@@ -98,7 +98,8 @@ size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset);
 /* The sampling behind TAMP_AMD_HINT_AUTO, for callers whose batch lives in device memory but who can show the library a
  * few streams on the host: looks at up to 64 of the n_streams streams (first 4 KiB each, HOST pointers) and returns
  * TAMP_AMD_HINT_RUNS or TAMP_AMD_HINT_PLAIN for TampAmdConf.input_hint.  Pure host code, no device needed. */
-uint8_t tamp_amd_input_hint(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, size_t n_streams);
+uint8_t tamp_amd_input_hint(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, size_t n_streams,
+                            int extended /* TampAmdConf.extended of the batch */);
 
 /* Number of visible HIP devices (0 when there is none), and the library version string. */
 int tamp_amd_device_count(void);

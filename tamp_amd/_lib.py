@@ -116,7 +116,7 @@ def load() -> C.CDLL:
     lib.tamp_compute_min_pattern_size.restype = C.c_int8
     lib.tamp_amd_compress_bound.argtypes = [sz, u8, i32]
     lib.tamp_amd_compress_bound.restype = sz
-    lib.tamp_amd_input_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, sz]
+    lib.tamp_amd_input_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, sz, i32]
     lib.tamp_amd_input_hint.restype = u8
     lib.tamp_amd_device_count.restype = i32
     lib.tamp_amd_version.restype = C.c_char_p

@@ -82,14 +82,14 @@ def _slab_offsets(caps: np.ndarray):
     return offs, int(caps.astype(np.uint64).sum())
 
 
-def input_hint(sample) -> bool:
+def input_hint(sample, extended: bool = True) -> bool:
     """The library's AUTO sampling on a host-side sample (list of bytes-likes): True when the run-aware build of the
     compress kernel should parse data like this (pass it as ``run_aware=`` for device batches)."""
     lib = _lib.load()
     flat, off, ln = pack_streams([bytes(x) for x in sample])
     if not len(ln):
         return False
-    return lib.tamp_amd_input_hint(flat.ctypes.data, off.ctypes.data, ln.ctypes.data, len(ln)) == 2
+    return lib.tamp_amd_input_hint(flat.ctypes.data, off.ctypes.data, ln.ctypes.data, len(ln), int(bool(extended))) == 2
 
 
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,

@@ -201,7 +201,7 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
 // where runs of 8+ equal bytes are frequent but do not make up most of the data (there the RLE path owns nearly every
 // position anyway) and the streams are long enough to amortise its per-epoch search (measured: Python sources 16 runs
 // per KiB, 19 % of the bytes -> 1.37x; 256-byte telemetry padded with spaces 4 per KiB, 73 % -> 0.87x).
-uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams) {
+uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams, bool extended) {
     uint64_t bytes = 0, runs = 0, in_runs = 0;
     const size_t step = n_streams > 64 ? n_streams / 64 : 1;
     for (size_t i = 0; i < n_streams; i += step) {
@@ -219,7 +219,11 @@ uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint3
     for (size_t i = 0; i < n_streams; i += step) total += in_len[i];
     const uint64_t sampled = (n_streams + step - 1) / step;
     const bool long_streams = total >= 1024 * sampled;
-    return (long_streams && bytes && runs * 1024 >= bytes && in_runs * 2 <= bytes) ? TAMP_AMD_HINT_RUNS : TAMP_AMD_HINT_PLAIN;
+    // v1 format: no RLE token takes the runs off the match finder's hands, so the run list pays however much of the
+    // data is runs (all zeros: 20 -> 1.3 ms for 4,096 x 4 KiB)
+    const bool many = runs * 1024 >= bytes;
+    const bool pays = extended ? (many && in_runs * 2 <= bytes) : (many || in_runs * 8 >= bytes);
+    return (long_streams && bytes && pays) ? TAMP_AMD_HINT_RUNS : TAMP_AMD_HINT_PLAIN;
 }
 
 int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
@@ -830,9 +834,10 @@ void tamp_window_copy(unsigned char* window, uint16_t* window_pos, uint16_t wind
     *window_pos = p;
 }
 
-uint8_t tamp_amd_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams) {
+uint8_t tamp_amd_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams,
+                            int extended) {
     if (!in || !in_off || !in_len || !n_streams) return TAMP_AMD_HINT_PLAIN;
-    return sample_input_hint(in, in_off, in_len, n_streams);
+    return sample_input_hint(in, in_off, in_len, n_streams, extended != 0);
 }
 
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset) {
@@ -930,7 +935,7 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         max_in_len = maxlen ? maxlen : 16;
     }
     TampAmdConf conf_resolved = *conf;
-    if (conf_resolved.input_hint == TAMP_AMD_HINT_AUTO) conf_resolved.input_hint = sample_input_hint(in, in_off, in_len, n_streams);
+    if (conf_resolved.input_hint == TAMP_AMD_HINT_AUTO) conf_resolved.input_hint = sample_input_hint(in, in_off, in_len, n_streams, conf->extended != 0);
     conf = &conf_resolved;
     const HostBatch b = {in, in_off, in_len, out, out_off, out_cap, out_len, status, nullptr, n_streams};
     std::vector<HostChunk> chunks;

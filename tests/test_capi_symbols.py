@@ -165,12 +165,12 @@ def test_input_hint_sampler_needs_no_device():
         pytest.skip("libtamp_amd.so not built")
     lib = _lib.load()
 
-    def hint(rows):
+    def hint(rows, extended=1):
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         n, L = rows.shape
         off = (np.arange(n, dtype=np.uint64) * L)
         ln = np.full(n, L, dtype=np.uint32)
-        return lib.tamp_amd_input_hint(rows.ctypes.data, off.ctypes.data, ln.ctypes.data, n)
+        return lib.tamp_amd_input_hint(rows.ctypes.data, off.ctypes.data, ln.ctypes.data, n, extended)
 
     PLAIN, RUNS = 1, 2
     assert hint(wl.synth_text(200, 4096)) == PLAIN
@@ -178,5 +178,6 @@ def test_input_hint_sampler_needs_no_device():
     rows = np.frombuffer(code.encode()[: 64 * 4096], dtype=np.uint8).reshape(64, 4096)
     assert hint(rows) == RUNS
     assert hint(np.zeros((64, 4096), np.uint8)) == PLAIN          # all one run: the RLE path owns it
+    assert hint(np.zeros((64, 4096), np.uint8), extended=0) == RUNS  # ... but not in the v1 format
     assert hint(wl.telemetry(4096, 256)) == PLAIN                  # short messages, mostly padding
-    assert lib.tamp_amd_input_hint(None, None, None, 0) == PLAIN
+    assert lib.tamp_amd_input_hint(None, None, None, 0, 1) == PLAIN
