@@ -265,6 +265,10 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     if (const char* e = getenv("TAMP_AMD_RUNS")) runlist = atoi(e) != 0;  // tuning / tests
     runlist = runlist && !a.lazy;
     a.blk = pick_block(W, max_in_len, packed, a.lazy != 0, runlist);
+    if (runlist && CompressLds(W, a.blk, packed, false, true).total > ctx->lds_per_block) {  // largest windows: no room
+        runlist = false;
+        a.blk = pick_block(W, max_in_len, packed, false, false);
+    }
     const CompressLds L(W, a.blk, packed, a.lazy != 0, runlist);
     if (L.total > ctx->lds_per_block) {
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);

@@ -1152,6 +1152,21 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 wk.nvalid = nvalid;
                 wk.ntok = 0, wk.ns = 0;
                 uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
+                uint32_t nqueued = 0;  // blocks whose tokens are still to be listed
+                auto list_queued = [&]() {
+                    __builtin_amdgcn_wave_barrier();
+                    if ((uint32_t)lane < nqueued) {
+                        uint32_t pp = segpos[lane];
+                        uint32_t slot = segbase[lane];
+                        for (uint32_t cleft = count8[pp]; cleft; cleft--) {
+                            toklist[slot++] = (uint16_t)pp;
+                            const uint32_t sv = steps[pp];
+                            pp += LAZY ? sv : (sv >= minp ? sv : 1u);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    nqueued = 0;
+                };
                 for (;;) {
                     if (wk.ntok + 72 > L.tokcap || wk.ns + 8 > kSlowCap) {
                         act = kActContinue;
@@ -1163,30 +1178,24 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         // Plain steps: hop from block to block through the jump tables (one dependent LDS read per 64
                         // positions / states), then let one lane per block list that block's tokens.
                         uint32_t pos = LAZY ? 2 * Walk::uni(wk.rd) + (wk.lazy_valid ? 1u : 0u) : Walk::uni(wk.rd);
-                        uint32_t total = 0, nseg = 0;
-                        while (pos < nv && nseg < 64 && wk.ntok + total + 64 <= L.tokcap) {
+                        // The blocks passed are queued (first position, first token slot); their tokens are listed
+                        // later, many blocks at a time (list_queued): a listing pass costs as many dependent LDS
+                        // round trips as the fullest block has tokens, however few blocks it serves.
+                        uint32_t total = 0, nhop = 0;
+                        while (pos < nv && nqueued < 64 && wk.ntok + total + 64 <= L.tokcap) {
                             const uint32_t jv = jump16[pos], cv = count8[pos];  // both reads in flight: one LDS round trip
                             const uint32_t j = Walk::uni(jv);
                             if (j == pos) break;  // a position the state machine has to look at
                             const uint32_t cpos = Walk::uni(cv);
                             if (lane == 0) {
-                                segpos[nseg] = (uint16_t)pos;
-                                segbase[nseg] = (uint16_t)total;
+                                segpos[nqueued] = (uint16_t)pos;
+                                segbase[nqueued] = (uint16_t)(wk.ntok + total);
                             }
-                            nseg++;
+                            nqueued++, nhop++;
                             total += cpos;
                             pos = j;
                         }
-                        __builtin_amdgcn_wave_barrier();
-                        if ((uint32_t)lane < nseg) {
-                            uint32_t pp = segpos[lane];
-                            uint32_t slot = wk.ntok + segbase[lane];
-                            for (uint32_t cleft = count8[pp]; cleft; cleft--) {
-                                toklist[slot++] = (uint16_t)pp;
-                                const uint32_t sv = steps[pp];
-                                pp += LAZY ? sv : (sv >= minp ? sv : 1u);
-                            }
-                        }
+                        if (nqueued > 64 - 34) list_queued();  // room for the next chain of hops (at most blk / 64 = 32 blocks)
                         wk.ntok += total;
                         if constexpr (LAZY) {
                             wk.rd = wk.wr = pos >> 1;
@@ -1198,7 +1207,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         } else {
                             wk.rd = wk.wr = pos;
                         }
-                        if (nseg) continue;
+                        if (nhop) continue;
                     }
                     const uint32_t p = w_p0 + wk.rd;
                     if (p < n) {
@@ -1252,6 +1261,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         break;
                     }
                 }
+                list_queued();
                 if (act == kActRebase) {
                     // drop the lag, keep the bytes a pending RLE run / extended match has consumed but not
                     // written (oracle/tamp_model.c m_epoch_begin)
