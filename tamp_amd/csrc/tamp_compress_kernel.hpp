@@ -74,7 +74,7 @@ struct CompressLds {
         // lazy matching walks (position, state) pairs: two table slots per position and the transitions themselves
         const uint32_t vblk = lazy ? 2 * blk : blk;
         jump = align_up(tokcap * 2, 16);
-        count = jump + vblk * 2;
+        count = jump + vblk * 2;  // (default parse: one u32 per position instead, jump | count << 16, at `jump`)
         vstep = count + vblk;
         ent = o;  // (W + blk) index entries (u32 packed, or u16 position-only for the largest windows);
                   // the walk reuses the space for the token list (tokcap x u16)
@@ -82,7 +82,7 @@ struct CompressLds {
             // after the match phase the same space holds the token list (tokcap x u16) and the per-position
             // jump tables of the walk: jump target (u16) and token count (u8)
             const uint32_t index_bytes = (W + blk + 16) * (packed ? 4u : 2u);
-            const uint32_t walk_bytes = align_up(tokcap * 2, 16) + vblk * 2 + vblk + 16 + (lazy ? vblk + 144 : 0);
+            const uint32_t walk_bytes = align_up(tokcap * 2, 16) + (lazy ? vblk * 2 + vblk + 16 + vblk + 144 : vblk * 4 + 16);
             o += align_up(index_bytes > walk_bytes ? index_bytes : walk_bytes, 16);
         }
         blen = o;
@@ -547,9 +547,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
     uint16_t* const jump16 = reinterpret_cast<uint16_t*>(smem + L.ent + L.jump);   // alias, same reason
     uint8_t* const count8 = smem + L.ent + L.count;                                 // alias, same reason
+    uint32_t* const jc32 = reinterpret_cast<uint32_t*>(smem + L.ent + L.jump);      // default parse: jump | count << 16
     uint8_t* const vstep = smem + L.ent + L.vstep;  // lazy builds: transition of every (position, state), same alias
-    uint16_t* const segpos = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048);      // alias: walk scratch
-    uint16_t* const segbase = reinterpret_cast<uint16_t*>(smem + L.cnt + 2048 + 256);
     uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
     uint8_t* const blen = smem + L.blen;
     uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
@@ -1139,8 +1138,12 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         if (!(st >> 16)) st = (o2 & 0x100FFu) | (((st >> 8) & 0xFFu) + ((o2 >> 8) & 0xFFu)) << 8;
                     }
                     if (b + lane < nv) {
-                        jump16[b + lane] = (uint16_t)(b + (st & 0xFFu));
-                        count8[b + lane] = (uint8_t)((st >> 8) & 0xFFu);
+                        if constexpr (LAZY) {
+                            jump16[b + lane] = (uint16_t)(b + (st & 0xFFu));
+                            count8[b + lane] = (uint8_t)((st >> 8) & 0xFFu);
+                        } else {
+                            jc32[b + lane] = (b + (st & 0xFFu)) | (((st >> 8) & 0xFFu) << 16);
+                        }
                     }
                 }
                 __syncthreads();
@@ -1153,12 +1156,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 wk.ntok = 0, wk.ns = 0;
                 uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
                 uint32_t nqueued = 0;  // blocks whose tokens are still to be listed
+                uint32_t segv = 0;     // lane k: first position | first token slot << 16 of queued block k
                 auto list_queued = [&]() {
                     __builtin_amdgcn_wave_barrier();
                     if ((uint32_t)lane < nqueued) {
-                        uint32_t pp = segpos[lane];
-                        uint32_t slot = segbase[lane];
-                        for (uint32_t cleft = count8[pp]; cleft; cleft--) {
+                        uint32_t pp = segv & 0xFFFFu;
+                        uint32_t slot = segv >> 16;
+                        for (uint32_t cleft = LAZY ? (uint32_t)count8[pp] : jc32[pp] >> 16; cleft; cleft--) {
                             toklist[slot++] = (uint16_t)pp;
                             const uint32_t sv = steps[pp];
                             pp += LAZY ? sv : (sv >= minp ? sv : 1u);
@@ -1183,14 +1187,16 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         // round trips as the fullest block has tokens, however few blocks it serves.
                         uint32_t total = 0, nhop = 0;
                         while (pos < nv && nqueued < 64 && wk.ntok + total + 64 <= L.tokcap) {
-                            const uint32_t jv = jump16[pos], cv = count8[pos];  // both reads in flight: one LDS round trip
-                            const uint32_t j = Walk::uni(jv);
-                            if (j == pos) break;  // a position the state machine has to look at
-                            const uint32_t cpos = Walk::uni(cv);
-                            if (lane == 0) {
-                                segpos[nqueued] = (uint16_t)pos;
-                                segbase[nqueued] = (uint16_t)(wk.ntok + total);
+                            uint32_t j, cpos;
+                            if constexpr (LAZY) {
+                                const uint32_t jv = jump16[pos], cv = count8[pos];  // both reads in flight: one LDS round trip
+                                j = Walk::uni(jv), cpos = Walk::uni(cv);
+                            } else {
+                                const uint32_t jc = Walk::uni(jc32[pos]);
+                                j = jc & 0xFFFFu, cpos = jc >> 16;
                             }
+                            if (j == pos) break;  // a position the state machine has to look at
+                            segv = (uint32_t)lane == nqueued ? (pos | ((wk.ntok + total) << 16)) : segv;  // lane k keeps block k
                             nqueued++, nhop++;
                             total += cpos;
                             pos = j;
