@@ -1128,15 +1128,20 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t sv = steps[b + lane];  // sentinels (0x80) beyond the last state
                     const bool slowp = (sv & 0x80u) != 0;
                     const uint32_t stepv = LAZY ? (sv & 0x7Fu) : (sv >= minp ? (sv & 0x1Fu) : 1u);
-                    // packed: target (relative, 0..79) | count << 8 | finished << 16
-                    uint32_t st = slowp ? ((uint32_t)lane | (1u << 16)) : (((uint32_t)lane + stepv) | (1u << 8));
-                    if ((st & 0xFFu) >= 64u) st |= 1u << 16;
+                    // packed: target * 4 (relative target 0..97 as the byte offset ds_bpermute wants) | count << 10 |
+                    // finished << 18.  A round is five VALU operations: the count field of the own state is added onto
+                    // the state fetched from the target (which brings target, count and the finished bit along; counts
+                    // stay below 256, nothing carries), finished lanes keep theirs.
+                    constexpr uint32_t kFin = 1u << 18, kCnt = 0xFFu << 10;
+                    uint32_t st = slowp ? (((uint32_t)lane << 2) | kFin) : ((((uint32_t)lane + stepv) << 2) | (1u << 10));
+                    if ((st & 0x3FFu) >= 256u) st |= kFin;
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
-                        const uint32_t tgt = (st >> 16) ? (uint32_t)lane : (st & 0xFFu);
-                        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tgt << 2), (int)st);
-                        if (!(st >> 16)) st = (o2 & 0x100FFu) | (((st >> 8) & 0xFFu) + ((o2 >> 8) & 0xFFu)) << 8;
+                        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(st & 0x3FFu), (int)st);
+                        const uint32_t nw = o2 + (st & kCnt);
+                        st = (st & kFin) ? st : nw;
                     }
+                    st = ((st & 0x3FFu) >> 2) | (((st >> 10) & 0xFFu) << 8);  // target | count << 8 for the stores below
                     if (b + lane < nv) {
                         if constexpr (LAZY) {
                             jump16[b + lane] = (uint16_t)(b + (st & 0xFFu));
