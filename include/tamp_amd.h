@@ -48,16 +48,20 @@ typedef struct TampAmdConf {
     uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
     uint8_t lazy_matching;         /* compressor.c:576-619; a bit over half the default mode's speed */
     uint8_t input_hint;            /* TAMP_AMD_HINT_*: which build of the compress kernel parses the batch (same bytes
-                                      either way).  AUTO: host-memory batches are sampled on the host (runs of 8+ equal
-                                      bytes per KiB, share of bytes inside them); device-memory batches take PLAIN. */
+                                      either way).  AUTO: host-memory batches are sampled on the host (stream length,
+                                      runs of 8+ equal bytes per KiB, share of bytes inside them); device-memory batches
+                                      take RUNS when max_in_len is 0 or >= 1024, else PLAIN. */
     uint8_t reserved;
 } TampAmdConf;
 
 enum {
     TAMP_AMD_HINT_AUTO = 0,
-    TAMP_AMD_HINT_PLAIN = 1, /* every buffer position in the bigram index: fastest on text without long runs */
-    TAMP_AMD_HINT_RUNS = 2,  /* long runs of one byte (indentation, rulers, padding) are listed once instead of being
-                                indexed byte by byte: 1.4x on source code, 3 % slower where there are none */
+    TAMP_AMD_HINT_PLAIN = 1, /* lean build: every buffer position in the bigram index, every extended match searched;
+                                the faster one for short messages (256-byte telemetry) and for data that is mostly runs */
+    TAMP_AMD_HINT_RUNS = 2,  /* run-aware build: long runs of one byte (indentation, rulers, padding) are listed once
+                                instead of being indexed byte by byte, extended matches without a rival are settled
+                                without a window search: faster on streams of 1 KiB and more (config 2 by 5 %, source
+                                code by 40 %) */
 };
 
 /* Where the data pointers of a batch call live. */

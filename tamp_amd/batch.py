@@ -102,9 +102,10 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     torch CUDA uint8 tensor + CUDA ``in_off`` (int64) / ``in_len`` (int32) tensors (device, zero-copy).
     Stream ``i``'s output equals ``tamp.compress(stream_i, window=..., literal=..., dictionary=..., extended=...)``
     of the reference.  ``status[i]`` holds the reference's ``tamp_res`` code for that stream.
-    ``run_aware`` picks the kernel build (same bytes either way): True for inputs with many runs of 8+ equal bytes
-    (source code, formatted text), False for plain text, None lets the library sample host batches (device batches
-    take the plain build).
+    ``run_aware`` picks the kernel build (same bytes either way): True = the run-aware build (long runs listed once,
+    most extended matches settled without a search: faster for streams of 1 KiB and more), False = the lean build
+    (faster for short messages), None = the library decides (host batches are sampled; device batches go by
+    ``max_in_len``).
     """
     lib = _lib.load()
     conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching, run_aware)

@@ -48,6 +48,7 @@ struct CompressArgs {
     int8_t* status;
     const uint8_t* dict;  // 1<<wbits bytes: the custom dictionary or the seeded default
     uint32_t n_streams;
+    uint32_t first_stream;  // stream index of workgroup 0 (batches above 2^20 streams take several launches)
     uint32_t blk;  // epoch block: positions matched per epoch (multiple of 64)
     uint8_t wbits, lbits, extended, dict_reset, lazy;
     // Segment mode (streaming Compressor over the engine, compressor.c:227-241,728-810): what opens the output, what
@@ -531,7 +532,13 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // PACKED: u32 index entries (position | rest of bigram | next byte | 3 bits of the one after); otherwise u16
 // positions only (window 2^15, where packed entries would not fit in 160 KiB of LDS).
 // LAZY: lazy matching (compressor.c:576-619) compiled in; the default build carries none of its code.
-template <bool PACKED, bool LAZY, bool RUNS = false>
+// WSCAN != 0: the window size as a compile-time constant, used by the bucket-scan loop ONLY (the launcher passes it for
+// the common 2^10 window).  The loop's range / limit constants then are immediates instead of scalar registers; with
+// them in registers the allocator, short of scalar registers everywhere in this kernel, sometimes reloads a spilled one
+// inside that loop (v_readlane + s_nop per entry: 4 % of the kernel, the "same code, 4 % slower" builds of section 3.6
+// of DESIGN.md).  Making W a constant for the whole kernel lets the compiler unroll and hoist elsewhere and costs 50+
+// spilled VGPRs, hence the narrow use.
+template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0>
 __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a) {
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -575,7 +582,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier of the first stream
     if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier)
 
+    // One stream per workgroup (the launcher splits batches above 2^20 streams into several launches): with no
+    // stream loop around it the compiler need not keep the batch tables' pointers alive past this point.
+#ifdef TAMP_STREAM_LOOP
     for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
+#else
+    const uint32_t s = blockIdx.x + a.first_stream;
+    {
+#endif
         // per-stream table entries are wave-uniform but arrive through vector loads (the compiler cannot prove the
         // tables invariant): pin them to scalar registers, or the two base pointers sit in VGPR pairs -- and spill
         const uint8_t* const in = a.in + uni_u64(a.in_off[s]);
@@ -857,6 +871,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
                         TAMP_FINE(f0);
                         if constexpr (!LAZY) {
+                            const uint32_t Ws = WSCAN ? WSCAN : W;  // (see the template parameter)
                             while (sl < s_hi) {
 #ifdef TAMP_PROF
                                 niter++;
@@ -868,11 +883,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                 const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
                                 const uint32_t c = e & 0xFFFFu;
                                 const uint32_t d = c - q;              // distance from the oldest window byte
-                                const uint32_t i = (e + e_wp) & mask;  // window index (payload bits masked off)
+                                const uint32_t i = (e + e_wp) & (Ws - 1);  // window index (payload bits masked off)
                                 // in the window and the same bigram.  (Index W-1 cannot start a match: its limit
                                 // W - i = 1 rejects it below.)
-                                if (d <= W - 2 && (x & ((1u << kRemBits) - 1)) == 0) {
-                                    const uint32_t t = W - d;  // bytes before the candidate reaches the newest byte
+                                if (d <= Ws - 2 && (x & ((1u << kRemBits) - 1)) == 0) {
+                                    const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
                                     if (t < 16) {
                                         wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
                                     } else {
@@ -882,7 +897,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                         // key = length << 16 | (W - index): longest, then lowest index.  W - i is also
                                         // the limit "may not run past index W-1"; a clipped length of 1 (index W-1)
                                         // yields a key below every real match and is read as "no match" later.
-                                        const uint32_t lim_i = W - i;
+                                        const uint32_t lim_i = Ws - i;
                                         key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
                                     }
                                 }
