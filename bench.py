@@ -142,7 +142,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc_traffic_bytes(),
-            "traffic_source": "profiles/r1i_pmc_{fetch,write}_counter_collection.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+            "traffic_source": "profiles/r1j_pmc_{fetch,write}_counter_collection.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "(separate passes) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) "
                               "+ WRITE_SIZE KB (DESIGN.md 3.3)",
             "kernel_ms": round(k_ms, 4),
@@ -190,8 +190,8 @@ def pmc_traffic_bytes():
         return sum(vals) / len(vals)
 
     try:
-        fetch_kb = mean_kb("r1i_pmc_fetch_counter_collection.csv")
-        write_kb = mean_kb("r1i_pmc_write_counter_collection.csv")
+        fetch_kb = mean_kb("r1j_pmc_fetch_counter_collection.csv")
+        write_kb = mean_kb("r1j_pmc_write_counter_collection.csv")
         return int(2 * fetch_kb * 1024 + write_kb * 1024)
     except Exception:
         return None

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the compress kernel.  Separate passes: kernel-trace/stats alone; each --pmc group alone
 # (FETCH_SIZE and WRITE_SIZE do not fit into one pass).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_r1i; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/pmc_r1j; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1
@@ -15,12 +15,12 @@ ls $OUT
 cat $OUT/bench.json
 python - <<'PY'
 import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/pmc_r1i/*counter_collection.csv')):
+for f in sorted(glob.glob('gpurun_out/pmc_r1j/*counter_collection.csv')):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if 'tamp_compress' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     print(f.split('/')[-1], {k: sum(v)/len(v) for k, v in acc.items()}, 'launches', {k: len(v) for k,v in acc.items()})
-for r in csv.DictReader(open('gpurun_out/pmc_r1i/stats_kernel_stats.csv')):
+for r in csv.DictReader(open('gpurun_out/pmc_r1j/stats_kernel_stats.csv')):
     if 'tamp' in r['Name']: print(r)
 PY
