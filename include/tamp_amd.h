@@ -49,7 +49,7 @@ typedef struct TampAmdConf {
     uint8_t lazy_matching;         /* compressor.c:576-619; a bit over half the default mode's speed */
     uint8_t input_hint;            /* TAMP_AMD_HINT_*: which build of the compress kernel parses the batch (same bytes
                                       either way).  AUTO: host-memory batches are sampled on the host (stream length,
-                                      runs of 8+ equal bytes per KiB, share of bytes inside them); device-memory batches
+                                      share of bytes inside runs of 8+ equal bytes); device-memory batches
                                       take RUNS when max_in_len is 0 or >= 1024, else PLAIN. */
     uint8_t reserved;
 } TampAmdConf;

@@ -197,12 +197,13 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     return blk;
 }
 
-// TAMP_AMD_HINT_AUTO for host-memory batches: look at up to 64 streams (first 4 KiB each).  The run-aware build pays
-// where runs of 8+ equal bytes are frequent but do not make up most of the data (there the RLE path owns nearly every
-// position anyway) and the streams are long enough to amortise its per-epoch search (measured: Python sources 16 runs
-// per KiB, 19 % of the bytes -> 1.37x; 256-byte telemetry padded with spaces 4 per KiB, 73 % -> 0.87x).
+// TAMP_AMD_HINT_AUTO for host-memory batches: look at up to 64 streams (first 4 KiB each).  The run-aware build is the
+// faster one for streams of 1 KiB and more (it settles most extended matches without a window search, and lists long
+// runs instead of indexing them byte by byte) -- unless, in the extended format, most of the data sits in runs of 8+
+// bytes: the RLE path owns nearly every position then and the run search is pure overhead (all zeros: 1.7 against
+// 2.3 ms).  Short messages take the lean build (256-byte telemetry: 2.2 against 2.5 ms).
 uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams, bool extended) {
-    uint64_t bytes = 0, runs = 0, in_runs = 0;
+    uint64_t bytes = 0, in_runs = 0;
     const size_t step = n_streams > 64 ? n_streams / 64 : 1;
     for (size_t i = 0; i < n_streams; i += step) {
         const uint8_t* p = in + in_off[i];
@@ -211,7 +212,7 @@ uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint3
         for (uint32_t k = 0; k < n;) {
             uint32_t e = k + 1;
             while (e < n && p[e] == p[k]) e++;
-            if (e - k >= 8) runs++, in_runs += e - k;
+            if (e - k >= 8) in_runs += e - k;
             k = e;
         }
     }
@@ -221,8 +222,7 @@ uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint3
     const bool long_streams = total >= 1024 * sampled;
     // v1 format: no RLE token takes the runs off the match finder's hands, so the run list pays however much of the
     // data is runs (all zeros: 20 -> 1.3 ms for 4,096 x 4 KiB)
-    const bool many = runs * 1024 >= bytes;
-    const bool pays = extended ? (many && in_runs * 2 <= bytes) : (many || in_runs * 8 >= bytes);
+    const bool pays = !extended || in_runs * 2 <= bytes;
     return (long_streams && bytes && pays) ? TAMP_AMD_HINT_RUNS : TAMP_AMD_HINT_PLAIN;
 }
 

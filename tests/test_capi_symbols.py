@@ -154,8 +154,8 @@ def test_window_copy_host_helper():
 
 
 def test_input_hint_sampler_needs_no_device():
-    """tamp_amd_input_hint (the sampling behind TAMP_AMD_HINT_AUTO): run-aware build for indented / ruled text of
-    4 KiB streams, plain build for the synthetic text, for data that is mostly runs, and for short messages."""
+    """tamp_amd_input_hint (the sampling behind TAMP_AMD_HINT_AUTO): run-aware build for streams of 1 KiB and more,
+    lean build for short messages and, in the extended format, for data that is mostly runs."""
     import numpy as np
 
     from tamp_amd import _lib
@@ -173,7 +173,7 @@ def test_input_hint_sampler_needs_no_device():
         return lib.tamp_amd_input_hint(rows.ctypes.data, off.ctypes.data, ln.ctypes.data, n, extended)
 
     PLAIN, RUNS = 1, 2
-    assert hint(wl.synth_text(200, 4096)) == PLAIN
+    assert hint(wl.synth_text(200, 4096)) == RUNS                  # streams of 1 KiB and more
     code = ("def frobnicate(x, y=None):\n        return x + 1 if y is None else compute(x, y)\n\n" + "# " + "-" * 12 + " helpers\n            if x and not y:\n                raise ValueError(x)\n") * 2200
     rows = np.frombuffer(code.encode()[: 64 * 4096], dtype=np.uint8).reshape(64, 4096)
     assert hint(rows) == RUNS
