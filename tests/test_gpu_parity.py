@@ -225,6 +225,31 @@ def test_run_aware_build_matches_oracle(ta, oracle):
         assert res.stream(j) == want.stream(j), j
 
 
+def test_more_streams_than_one_launch_holds(ta, oracle):
+    """One stream per workgroup: a batch above 2^20 streams takes several launches (first_stream); every stream must
+    still come out, in place."""
+    import torch
+
+    n, L = (1 << 20) + 4099, 24
+    rng = np.random.default_rng(3)
+    rows = rng.integers(97, 101, (n, L), dtype=np.uint8)          # four letters: short matches, a few runs
+    rows[:, :4] = np.frombuffer(np.arange(n, dtype=np.uint32).tobytes(), dtype=np.uint8).reshape(n, 4) | 0x40
+    dev = torch.device("cuda:0")
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off = torch.arange(n, dtype=torch.int64, device=dev) * L
+    ln = torch.full((n,), L, dtype=torch.int32, device=dev)
+    res = ta.compress_batch(data, off, ln, max_in_len=L)
+    assert bool((res.status == 0).all().item())
+    sel = [0, 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, n - 1] + [int(x) for x in rng.integers(0, n, 200)]
+    for i in sel:
+        st, want = oracle.compress(rows[i].tobytes())
+        assert st == 0 and res.stream(i) == want, i
+    back = ta.decompress_batch(res.out, res.out_off, res.out_len, out_cap=L + 8)
+    assert bool((back.status == 2).all().item()) and bool((back.out_len == L).all().item())
+    got = back.out.view(-1)[: n * (L + 8)].view(n, L + 8)[:, :L]
+    assert bool((got == data.view(n, L)).all().item())
+
+
 def test_excess_bits_and_invalid_conf(ta, oracle):
     from tamp_amd import workloads as wl
 
