@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W            one process drives N devices, one hipStream each
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+                                                             one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE)
 
-Workload (BASELINE.json configs[1]): per GPU, 65,536 independent 4 KiB synthetic-text
-streams, window=10 literal=8, library-default extended=1, batch-compressed by the HIP kernels with the inputs
-already resident in HBM.  One "step" = one batch launch over all streams of the rank.  Streams shard
-embarrassingly across ranks (weak scaling, no data-path collective); rank r owns stream indices
-[r*65536, (r+1)*65536).  Prints ONE JSON line on rank 0.
+Workload, default (BASELINE.json configs[1]): per GPU 65,536 independent 4 KiB synthetic-text
+streams, window=10 literal=8, library-default extended=1, batch-compressed by the HIP kernels with the inputs already
+resident in HBM.  One "step" = one batch launch over all streams of every shard.  Streams shard embarrassingly (weak
+scaling, NO collective on the data path, RCCL is never initialised): shard r owns stream indices [r*65536, (r+1)*65536).
+With --corpus PATH (or $TAMP_CORPUS) the workload is configs[2]: the file cut into independent 4 KiB streams (the short
+tail kept as a last stream), the streams cut into N contiguous ranges balanced by bytes (strong scaling); every stream
+is checked against the reference C, and a 100,000,000-byte file is also compressed as ONE stream and compared with the
+reference's whole-file pins for enwik8 (/root/reference/tests/test_dataset_regression.py:38-43, README.md:266).
+Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,6 +27,75 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_TAG = "r2"     # profiles/<tag>_pmc_{fetch,write}_counter_collection.csv feed roofline.traffic
+
+
+class Shard:
+    """One contiguous range of streams resident on one device, with its own HIP stream."""
+
+    def __init__(self, torch, index, device, flat, in_off, in_len, max_len, conf_kw):
+        import numpy as np
+        import tamp_amd
+
+        self.index, self.device = index, device
+        self.n = int(len(in_len))
+        self.in_bytes = int(np.asarray(in_len, dtype=np.uint64).sum())
+        self.max_len = int(max_len)
+        with torch.cuda.device(device):
+            self.stream = torch.cuda.Stream(device=device)
+            self.data = torch.from_numpy(np.ascontiguousarray(flat)).to(device)
+            self.off = torch.from_numpy(np.asarray(in_off, dtype=np.int64)).to(device)
+            self.len = torch.from_numpy(np.asarray(in_len, dtype=np.int32)).to(device)
+            cap1 = tamp_amd.compress_bound(self.max_len, 8)
+            self.cap = torch.full((self.n,), cap1, dtype=torch.int32, device=device)
+        self.kw = dict(conf_kw, max_in_len=self.max_len, out_cap=self.cap)
+        self.torch = torch
+        self.events = []
+
+    def launch(self, record=False, **over):
+        """Enqueue one batch compress on this shard's stream (asynchronous); optionally bracket it with HIP events."""
+        import tamp_amd
+
+        torch = self.torch
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+            res = tamp_amd.compress_batch(self.data, self.off, self.len, stream=self.stream.cuda_stream,
+                                          **dict(self.kw, **over))
+            if record:
+                e1.record(self.stream)
+                self.events.append((e0, e1))
+        return res
+
+    def sync(self):
+        self.stream.synchronize()
+
+
+def host_threads():
+    """CPUs this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, quota) if quota else n), n, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -28,90 +103,117 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (synthetic workload)")
     ap.add_argument("--stream-len", type=int, default=4096)
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--extended", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=65536, help="streams timed on the host cores")
+    ap.add_argument("--corpus", default=os.environ.get("TAMP_CORPUS"), help="file to cut into 4 KiB streams (configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="timed loop only (profiling runs)")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="streams timed on the host cores")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
     import tamp_amd
+    from tamp_amd import partition_streams
     from tamp_amd import workloads as wl
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = env_world > 1  # one rank per GPU under torch.distributed.run
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    world = env_world if launched else max(1, args.gpus)
+    if launched and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    one_device = os.environ.get("TAMP_BENCH_ONE_DEVICE") == "1"  # every shard on cuda:0 (launch-path test on a 1-GPU box)
+    ndev = torch.cuda.device_count()
+    if not one_device and not launched and world > ndev:
+        raise SystemExit(f"--gpus {world} but only {ndev} device(s) visible (TAMP_BENCH_ONE_DEVICE=1 maps every shard to cuda:0)")
+    dist = None
+    if launched:
+        # The data path needs no collective: the process group exists for the barrier and the MAX of elapsed time only,
+        # over gloo (CPU); RCCL is never initialised.
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # TAMP_BENCH_ONE_DEVICE=1: every rank on cuda:0 with gloo for the barrier / max -- a launcher-path smoke test
-        # for boxes with a single GPU; real runs use one device per rank and RCCL.
-        one_device = os.environ.get("TAMP_BENCH_ONE_DEVICE") == "1"
+        dist.init_process_group("gloo")
+    my_shards = [rank] if launched else list(range(world))
+
+    def device_of(r):
         if one_device:
-            local_rank = 0
-            dist.init_process_group("gloo")
+            return torch.device("cuda", 0)
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if launched else r)
+
+    conf_kw = dict(window=args.window, literal=8, extended=bool(args.extended))
+    corpus_blob = None
+    if args.corpus:
+        corpus_blob = open(args.corpus, "rb").read()
+        flat, in_off, in_len = wl.split_fixed(corpus_blob, args.stream_len, keep_tail=True)
+        ranges = partition_streams(in_len, world)
+    shards = []
+    for r in my_shards:
+        if corpus_blob is not None:
+            b, e = ranges[r]
+            lo = int(in_off[b]) if e > b else 0
+            hi = int(in_off[e - 1] + in_len[e - 1]) if e > b else 0
+            shards.append(Shard(torch, r, device_of(r), flat[lo:hi], in_off[b:e] - np.uint64(lo), in_len[b:e],
+                                args.stream_len, conf_kw))
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    n, slen = args.streams, args.stream_len
-    rows = wl.synth_text(n, slen, first_index=rank * n)
-    in_off, in_len = wl.csr_for_fixed(n, slen)
-    data = torch.from_numpy(rows.reshape(-1)).to(dev)
-    off_t = torch.from_numpy(in_off.astype(np.int64)).to(dev)
-    len_t = torch.from_numpy(in_len.astype(np.int32)).to(dev)
-    cap1 = tamp_amd.compress_bound(slen, 8)
-    cap_t = torch.full((n,), cap1, dtype=torch.int32, device=dev)
-    kw = dict(window=args.window, literal=8, extended=bool(args.extended), max_in_len=slen, out_cap=cap_t)
-
-    def step(timing=False):
-        return tamp_amd.compress_batch(data, off_t, len_t, timing=timing, **kw)
+            rows = wl.synth_text(args.streams, args.stream_len, first_index=r * args.streams)
+            off, ln = wl.csr_for_fixed(args.streams, args.stream_len)
+            sh = Shard(torch, r, device_of(r), rows.reshape(-1), off, ln, args.stream_len, conf_kw)
+            sh.rows = rows
+            shards.append(sh)
 
     def fence():
-        torch.cuda.synchronize(dev)
-        if distributed:
+        for sh in shards:
+            sh.sync()
+        if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        for sh in shards:
+            sh.sync()
 
+    res = None
     for _ in range(args.warmup):
-        res = step()
+        res = [sh.launch() for sh in shards]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        res = [sh.launch(record=True) for sh in shards]
     fence()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    status_ok = bool((res.status == 0).all().item())
-    out_bytes = int(res.out_len.to(torch.int64).sum().item())
-    in_bytes = n * slen
-    total_in = in_bytes * world * args.steps
-    value = total_in / elapsed / 1e6
+    in_bytes = sum(sh.in_bytes for sh in shards)      # this process, one step
+    out_bytes = sum(int(r.out_len.to(torch.int64).sum().item()) for r in res)
+    status_ok = all(bool((r.status == 0).all().item()) for r in res)
+    n_streams = sum(sh.n for sh in shards)
+    totals = [in_bytes, out_bytes, n_streams, int(status_ok)]
+    if dist is not None:
+        tt = torch.tensor(totals, dtype=torch.int64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        totals = tt.tolist()
+        totals[3] = int(totals[3] == world)
+    job_in, job_out, job_streams, job_ok = totals
+    value = job_in * args.steps / elapsed / 1e6
 
-    # kernel-only duration: re-time a few launches with hipEvents one at a time (event pair per launch)
-    ev_ms = []
-    for _ in range(min(10, max(3, args.steps))):
-        r = step(timing=True)
-        ev_ms.append(float(r.kernel_ms))
-    torch.cuda.synchronize(dev)
-    k_ms = float(np.mean(ev_ms))
-    alg_bytes = in_bytes + out_bytes  # B_alg = in_len + out_len per stream
+    # dominant kernel: HIP events recorded around every launch of the timed region, on the launch stream
+    sh0 = shards[0]
+    ev = [a.elapsed_time(b) for sh in shards for (a, b) in sh.events]
+    k_ms = float(np.mean([a.elapsed_time(b) for (a, b) in sh0.events])) if sh0.events else float("nan")
+    alg_bytes = sh0.in_bytes + int(res[0].out_len.to(torch.int64).sum().item())  # in_len + out_len
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    if corpus_blob is not None:
+        workload = (f"configs[2]: {os.path.basename(args.corpus)} ({len(corpus_blob)} B) cut into {job_streams} independent "
+                    f"streams of {args.stream_len} B (short tail kept as the last stream), window={args.window} literal=8 "
+                    f"extended={args.extended}, contiguous stream ranges balanced by bytes over {world} GPU(s), inputs resident in HBM")
+    else:
+        workload = (f"configs[1]: {args.streams} x {args.stream_len} B synthetic-text streams per GPU, window={args.window} "
+                    f"literal=8 extended={args.extended}, one batch launch per step and GPU, inputs resident in HBM")
     result = {
         "metric": "input MB/s, 4KiB-chunk batch compress window=10 (bit-exact vs C ref)",
         "value": round(value, 2),
@@ -121,18 +223,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if corpus_blob is not None else "weak",
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
+        "data": ("real: " + os.path.basename(args.corpus) + " sha256=" + hashlib.sha256(corpus_blob).hexdigest()[:16])
+                if corpus_blob is not None else "synthetic",
         "config": {
-            "workload": f"configs[1]: {n} x {slen} B synthetic-text streams per GPU, window={args.window} literal=8 "
-                        f"extended={args.extended}, one batch launch per step, inputs resident in HBM",
-            "streams_per_gpu": n,
-            "stream_len": slen,
-            "parallelism": f"streams sharded over {world} GPU(s), no collective",
-            "compressed_ratio": round(out_bytes / in_bytes, 4),
-            "all_streams_ok": status_ok,
+            "workload": workload,
+            "streams_total": job_streams,
+            "stream_len": args.stream_len,
+            "parallelism": (f"{world} rank(s), one GPU each (torch.distributed.run; gloo barrier + MAX only)" if launched else
+                            f"one process, {world} device(s), one hipStream per device") + ", streams sharded, no collective"
+                           + (" [TAMP_BENCH_ONE_DEVICE: all shards on cuda:0]" if one_device else ""),
+            "compressed_ratio": round(job_out / max(job_in, 1), 4),
+            "all_streams_ok": bool(job_ok),
         },
         "roofline": {
             "bound": "hbm",
@@ -141,117 +245,216 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc_traffic_bytes(),
-            "traffic_source": "profiles/r1j_pmc_{fetch,write}_counter_collection.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                              "(separate passes) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) "
-                              "+ WRITE_SIZE KB (DESIGN.md 3.3)",
+            "traffic": None,
             "kernel_ms": round(k_ms, 4),
+            "kernel_ms_minmax_all_shards": [round(min(ev), 4), round(max(ev), 4)] if ev else None,
+            "timing": f"hipEvent pairs around each of the {len(sh0.events)} launches of the timed region on shard 0's stream",
             "algorithmic_bytes_per_launch": alg_bytes,
-            "read_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "read_frac": round(sh0.in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         },
     }
+    traffic, src = pmc_traffic_bytes()
+    if corpus_blob is None and args.streams == 65536 and args.stream_len == 4096:
+        result["roofline"]["traffic"] = traffic
+        result["roofline"]["traffic_source"] = src
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, rows, res, np)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (profiling runs pass --no-cpu-baseline: timed loop only)
-        # Not part of the metric: the same batch in the v1 format and the decode of what was just produced (round trip
-        # checked), kernel time by hipEvents, for the record next to the headline number.
+    extras = rank == 0 and not args.no_cpu_baseline
+    if extras and world == 1:
+        result["cpu_baseline"] = cpu_baseline(args, sh0, res[0], np, corpus_blob is not None)
+    if extras and corpus_blob is not None:
         try:
-            also = {}
-            ms = min(float(tamp_amd.compress_batch(data, off_t, len_t, timing=True, **dict(kw, extended=False)).kernel_ms)
-                     for _ in range(3))
-            also["compress_v1_format_MBps"] = round(in_bytes / (ms * 1e-3) / 1e6, 1)
-            back = None
-            ms = 1e30
-            for _ in range(3):
-                back = tamp_amd.decompress_batch(res.out, res.out_off, res.out_len, out_cap=slen, timing=True)
-                ms = min(ms, float(back.kernel_ms))
-            ok = bool((back.out_len == slen).all().item()) and bool(torch.equal(back.out[: n * slen], data[: n * slen]))
-            also["decompress_output_MBps"] = round(in_bytes / (ms * 1e-3) / 1e6, 1)
-            also["decompress_round_trip"] = "bit-exact" if ok else "MISMATCH"
-            result["also"] = also
-        except Exception as e:  # the extras must never cost the bench line
-            result["also"] = {"error": repr(e)[:200]}
+            result["corpus_pins"] = corpus_pins(args, corpus_blob, torch, np)
+        except Exception as e:
+            result["corpus_pins"] = {"error": repr(e)[:200]}
+    if extras and world == 1 and corpus_blob is None:
+        # Not part of the metric (informational, each guarded): the v1 format, the decode of what was just produced,
+        # and real text found on this machine next to the synthetic headline.
+        also = {}
+        try:
+            also.update(also_v1_and_decode(sh0, res[0], torch))
+        except Exception as e:
+            also["error"] = repr(e)[:200]
+        try:
+            also["real_text"] = also_real_text(args, torch, np)
+        except Exception as e:
+            also["real_text"] = {"error": repr(e)[:200]}
+        result["also"] = also
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if distributed:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per launch of the compress kernel from the committed rocprofv3 PMC summaries (bench.py cannot run the
-    profiler on itself); None if they are missing."""
+    """HBM bytes per launch of the compress kernel from the committed rocprofv3 PMC summaries of this command (bench.py
+    cannot run the profiler on itself); (None, reason) if they are missing."""
     import csv
 
     def mean_kb(name):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        path = os.path.join(ROOT, "profiles", name)
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "tamp_compress" in r["Kernel_Name"]]
         return sum(vals) / len(vals)
 
-    try:
-        fetch_kb = mean_kb("r1j_pmc_fetch_counter_collection.csv")
-        write_kb = mean_kb("r1j_pmc_write_counter_collection.csv")
-        return int(2 * fetch_kb * 1024 + write_kb * 1024)
-    except Exception:
-        return None
+    for tag in (PROFILE_TAG, "r1j"):
+        try:
+            fetch_kb = mean_kb(f"{tag}_pmc_fetch_counter_collection.csv")
+            write_kb = mean_kb(f"{tag}_pmc_write_counter_collection.csv")
+        except Exception:
+            continue
+        return int(2 * fetch_kb * 1024 + write_kb * 1024), (
+            f"profiles/{tag}_pmc_{{fetch,write}}_counter_collection.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+            "passes, tools/pmc_run.sh) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) + "
+            "WRITE_SIZE KB" + ("" if tag == PROFILE_TAG else " [STALE: captured on an earlier build of the kernel]"))
+    return None, "no committed PMC pass"
 
 
-def cpu_baseline(args, rows, gpu_res, np):
-    """The reference C (oracle/_ref, kind "reference") or this repo's restatement (kind "port") timed on the
-    host cores on a bounded sample of the same workload; its output doubles as the parity check of the GPU run."""
+def _checker():
     from oracle.checker import Oracle, Ref
-    from tamp_amd import workloads as wl
 
-    cores = os.cpu_count() or 1
-    quota = None
-    try:  # cgroup v2 CPU quota of the container ("max" = unlimited)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = max(1, int(int(q) / int(per)))
-    except (OSError, ValueError):
-        pass
-    sample = min(args.cpu_sample, rows.shape[0])
-    sub = rows[:sample]
-    off, ln = wl.csr_for_fixed(sample, rows.shape[1])
-    kind, impl = ("reference", Ref()) if Ref.available() else ("port", Oracle())
+    return ("reference", Ref()) if Ref.available() else ("port", Oracle())
+
+
+def cpu_baseline(args, shard, gpu_res, np, from_corpus):
+    """The reference C (oracle/_ref, kind "reference") or this repo's restatement (kind "port") timed on the host cores
+    this process may use, on a bounded sample of the same workload; its output doubles as the parity check of the GPU
+    run.  Method of BASELINE.md section 3: one pthread per usable core, 3 warm runs, best of 5."""
+    kind, impl = _checker()
+    threads, affinity, quota = host_threads()
+    sample = min(args.cpu_sample, shard.n)
+    off = shard.off[:sample].cpu().numpy().astype(np.uint64)
+    ln = shard.len[:sample].cpu().numpy().astype(np.uint32)
+    hi = int(off[-1] + ln[-1])
+    sub = shard.data[:hi].cpu().numpy()
     kw = dict(window=args.window, literal=8, extended=bool(args.extended))
-    # the box may expose more logical CPUs than the container may use: pick the thread count on a small probe
-    probe = min(sample, 4096)
-    poff, pln = wl.csr_for_fixed(probe, rows.shape[1])
-    cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16, 8, quota or cores) if 1 <= c <= cores})
-    rates = {}
-    for c in cands:
-        r = impl.compress_batch(sub[:probe].reshape(-1), poff, pln, threads=c, **kw)
-        rates[c] = probe * rows.shape[1] / r.seconds
-    top = max(rates.values())
-    threads = min(c for c in cands if rates[c] >= 0.95 * top)  # fewest threads that reach the plateau
+    warm = sub[: min(hi, 8 << 20)]
+    wn = int(np.searchsorted(off + ln, warm.size, side="right"))
+    for _ in range(3):
+        if wn:
+            impl.compress_batch(warm, off[:wn], ln[:wn], threads=threads, **kw)
     best = None
-    for _ in range(2):
-        r = impl.compress_batch(sub.reshape(-1), off, ln, threads=threads, **kw)
+    for _ in range(5):
+        r = impl.compress_batch(sub, off, ln, threads=threads, **kw)
         if best is None or r.seconds < best.seconds:
             best = r
-    # parity of the GPU output against the baseline's output, stream by stream
     olen = gpu_res.out_len[:sample].cpu().numpy()
     ooff = gpu_res.out_off[:sample].cpu().numpy()
-    hi = int(ooff[-1] + olen[-1])
-    gout = gpu_res.out[:hi].cpu().numpy()
+    gout = gpu_res.out[: int(ooff[-1] + olen[-1])].cpu().numpy()
     mism = -1
     for i in range(sample):
         if gout[ooff[i] : ooff[i] + olen[i]].tobytes() != best.stream(i):
             mism = i
             break
     return {
-        "value": round(sub.size / best.seconds / 1e6, 2),
+        "value": round(hi / best.seconds / 1e6, 2),
         "unit": "MB/s",
         "cores": threads,
+        "threads": threads,
         "kind": kind,
-        "sample": f"first {sample} of the {rows.shape[0]} streams ({sub.size} B), {threads} pthreads "
-                  f"(os.cpu_count()={cores}, cgroup cpu quota={quota}; thread count chosen on a {probe}-stream probe), "
-                  "best of 2",
-        "per_core": round(sub.size / best.seconds / 1e6 / threads, 2),
-        "parity": "bit-exact" if mism < 0 else f"MISMATCH at stream {mism}",
+        "cpu_model": cpu_model(),
+        "sample": f"first {sample} of the {shard.n} streams ({hi} B), one pthread per usable CPU = {threads} "
+                  f"(affinity mask {affinity}, cgroup quota {quota}, os.cpu_count()={os.cpu_count()}), 3 warm runs, best of 5",
+        "per_core": round(hi / best.seconds / 1e6 / threads, 2),
+        "parity": (f"bit-exact, {sample} streams" if mism < 0 else f"MISMATCH at stream {mism}"),
     }
+
+
+def also_v1_and_decode(shard, res, torch):
+    import tamp_amd
+
+    out = {}
+    ms = []
+    for _ in range(3):
+        shard.events.clear()
+        shard.launch(record=True, extended=False)
+        shard.sync()
+        ms.append(shard.events[-1][0].elapsed_time(shard.events[-1][1]))
+    out["compress_v1_format_MBps"] = round(shard.in_bytes / (min(ms) * 1e-3) / 1e6, 1)
+    torch.cuda.synchronize(shard.device)
+    back, best = None, 1e30
+    with torch.cuda.device(shard.device):
+        for _ in range(3):
+            back = tamp_amd.decompress_batch(res.out, res.out_off, res.out_len, out_cap=shard.max_len, timing=True)
+            best = min(best, float(back.kernel_ms))
+    n = shard.n
+    ok = bool((back.out_len == shard.len).all().item())
+    if ok and shard.max_len * n == shard.in_bytes:
+        ok = bool(torch.equal(back.out[: shard.in_bytes], shard.data[: shard.in_bytes]))
+    comp_bytes = int(res.out_len.to(torch.int64).sum().item())
+    gbs = (comp_bytes + shard.in_bytes) / (best * 1e-3) / 1e9
+    out["decompress_output_MBps"] = round(shard.in_bytes / (best * 1e-3) / 1e6, 1)
+    out["decompress_round_trip"] = "bit-exact" if ok else "MISMATCH"
+    out["decompress"] = {"kernel_ms": round(best, 4), "roofline": {
+        "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+        "algorithmic_bytes_per_launch": comp_bytes + shard.in_bytes,
+        "note": "compressed bytes read + bytes written, hipEvents around the decode launch (header pre-pass included)"}}
+    return out
+
+
+def also_real_text(args, torch, np):
+    """Real text found on this machine (the metric's own corpus, enwik8, is not in the image): GB/s of input per corpus,
+    both formats, 16,384 x 4 KiB streams (the corpus repeated to fill them), with the first 512 streams of each checked
+    against the reference C."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    kind, impl = _checker()
+    dev = torch.device("cuda", 0)
+    n, L = 16384, 4096
+    out = {"streams": n, "stream_len": L, "checker": kind}
+    sources = {name: wl.real_text(name) for name in wl.REAL_TEXT_SOURCES}
+    sources["synthetic (configs[1] text)"] = None
+    for name, blob in sources.items():
+        if blob is not None and len(blob) < 64 * L:
+            out[name] = "not found on this machine"
+            continue
+        rows = wl.synth_text(n, L) if blob is None else wl.tile_rows(blob, n, L)
+        off, ln = wl.csr_for_fixed(n, L)
+        data = torch.from_numpy(rows.reshape(-1)).to(dev)
+        off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+        len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
+        entry = {"corpus_bytes": None if blob is None else len(blob)}
+        for ext in (True, False):
+            ms, r = [], None
+            for _ in range(3):
+                r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=L, timing=True, window=args.window, literal=8,
+                                            extended=ext)
+                ms.append(float(r.kernel_ms))
+            k = 512
+            want = impl.compress_batch(rows[:k].reshape(-1), off[:k], ln[:k], threads=host_threads()[0],
+                                       window=args.window, literal=8, extended=ext)
+            olen = r.out_len[:k].cpu().numpy()
+            ooff = r.out_off[:k].cpu().numpy()
+            gout = r.out[: int(ooff[-1] + olen[-1])].cpu().numpy()
+            ok = all(gout[ooff[i] : ooff[i] + olen[i]].tobytes() == want.stream(i) for i in range(k))
+            tag = "extended" if ext else "v1"
+            entry[tag + "_GBps"] = round(n * L / (min(ms) * 1e-3) / 1e9, 2)
+            entry[tag + "_ratio"] = round(float(r.out_len.to(torch.int64).sum().item()) / (n * L), 4)
+            entry[tag + "_parity_first_512"] = "bit-exact" if ok else "MISMATCH"
+        out[name] = entry
+    return out
+
+
+def corpus_pins(args, blob, torch, np):
+    """Whole-file pins of the reference for enwik8: the file as ONE stream, both formats, SHA-256 and size of the output
+    (tests/test_dataset_regression.py:38-43, README.md:266), plus the first 100 KB in the v1 format (README.md:336)."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    pins = wl.ENWIK8_PINS
+    if len(blob) != pins["len"]:
+        return {"checked": False, "why": f"file is {len(blob)} B, enwik8 is {pins['len']} B: no whole-file pin applies"}
+    out = {"checked": True}
+    for ext in (False, True):
+        r = tamp_amd.compress_batch([blob], window=10, literal=8, extended=ext)
+        got = r.stream(0)
+        tag = "extended" if ext else "v1"
+        out[tag] = {"size": len(got), "size_pin": pins[tag + "_size"], "sha256_matches_reference": hashlib.sha256(got).hexdigest() == pins[tag + "_sha256"]}
+    sizes = {("extended" if ext else "v1"): len(tamp_amd.compress_batch([blob[:100_000]], window=10, literal=8,
+                                                                          extended=ext).stream(0)) for ext in (False, True)}
+    out["first_100k"] = dict(sizes, size_pin=pins["first_100k_v1_size"],
+                             note="README.md:336 quotes one size for the first 100,000 bytes without naming the format")
+    return out
 
 
 if __name__ == "__main__":

@@ -125,7 +125,11 @@ const char *tamp_amd_last_error(void);
  *
  *   in[in_off[i] .. in_off[i]+in_len[i])        input bytes of stream i
  *   out[out_off[i] .. out_off[i]+out_cap[i])    output slab of stream i
- *   out_len[i]                                  bytes produced
+ *   out_len[i]                                  bytes produced.  Slab bytes behind out_len[i] are unspecified after
+ *                                               the call when the slabs tile the output buffer back to back (host
+ *                                               memory: the results come back in one transfer per chunk); with gaps
+ *                                               between slabs or permuted offsets only the out_len[i] produced bytes
+ *                                               of each slab are written, nothing else in the caller's buffer
  *   status[i]                                   TAMP_OK, TAMP_OUTPUT_FULL (slab too small; out_len[i] <= out_cap[i]
  *                                               bytes of valid prefix), TAMP_EXCESS_BITS (a literal does not fit
  *                                               conf->literal bits, compressor.c:629-631; out_len[i] = whole bytes
@@ -170,6 +174,10 @@ int tamp_batch_compress(const TampAmdConf *conf, const uint8_t *dictionary, cons
  *                                 one actually present; OR in TAMP_AMD_WINDOW_BITS_EXACT to skip that and stay fully
  *                                 asynchronous (windows are then sized for max_window_bits itself)
  *   in_consumed                   optional (may be NULL): compressed bytes consumed per stream
+ *   in_len[i]                     below 2^29 bytes (512 MiB) per stream: the decoders count bits in 32-bit registers;
+ *                                 a longer stream gets status TAMP_AMD_BAD_ARGUMENT and produces nothing.  Feed longer
+ *                                 streams in pieces through tamp_batch_decompress_resume, which looks at 2^28 bytes per
+ *                                 call at most and reports what it consumed.
  */
 int tamp_batch_decompress(const uint8_t *dictionary, size_t dictionary_len, uint8_t max_window_bits, const uint8_t *in,
                           const uint64_t *in_off, const uint32_t *in_len, uint8_t *out, const uint64_t *out_off,

@@ -34,6 +34,7 @@ class BatchResult:
     status: object       # int8 [n] -- tamp_res per stream
     in_consumed: object = None
     kernel_ms: float = -1.0
+    _keep: object = None  # device tensors the asynchronous launch still reads (converted tables, the dictionary)
 
     def stream(self, i: int) -> bytes:
         o, n = int(self.out_off[i]), int(self.out_len[i])
@@ -136,13 +137,15 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
         if dictionary is not None:
             dict_t = dictionary if _is_torch(dictionary) else torch.frombuffer(bytearray(dictionary), dtype=torch.uint8).to(dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.tamp_batch_compress(C.byref(conf), _ptr(dict_t), _ptr(data), _ptr(in_off.to(torch.int64)),
-                                     _ptr(in_len.to(torch.int32)), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
+        # the launch is asynchronous: converted copies of the tables must outlive it (they ride on the result)
+        in_off_t, in_len_t = in_off.to(torch.int64), in_len.to(torch.int32)
+        rc = lib.tamp_batch_compress(C.byref(conf), _ptr(dict_t), _ptr(data), _ptr(in_off_t),
+                                     _ptr(in_len_t), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
                                      _ptr(out_len_t), _ptr(status_t), n, int(max_in_len), _lib.MEM_DEVICE,
                                      dev.index or 0, C.c_void_p(st))
         _lib.check_launch(rc)
         ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
-        return BatchResult(out, out_off_t, out_len_t, status_t, None, ms)
+        return BatchResult(out, out_off_t, out_len_t, status_t, None, ms, (data, in_off_t, in_len_t, out_cap_t, dict_t))
 
     if in_off is None:
         flat, in_off, in_len = pack_streams(data)
@@ -206,13 +209,14 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
             dict_t = dictionary if _is_torch(dictionary) else torch.frombuffer(bytearray(dictionary), dtype=torch.uint8).to(dev)
             dict_len = int(dict_t.numel())
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.tamp_batch_decompress(_ptr(dict_t), dict_len, max_window_bits, _ptr(data), _ptr(in_off.to(torch.int64)),
-                                       _ptr(in_len.to(torch.int32)), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
+        in_off_t, in_len_t = in_off.to(torch.int64), in_len.to(torch.int32)  # kept alive on the result (async launch)
+        rc = lib.tamp_batch_decompress(_ptr(dict_t), dict_len, max_window_bits, _ptr(data), _ptr(in_off_t),
+                                       _ptr(in_len_t), _ptr(out), _ptr(out_off_t), _ptr(out_cap_t),
                                        _ptr(out_len_t), _ptr(status_t), _ptr(consumed_t), n, _lib.MEM_DEVICE,
                                        dev.index or 0, C.c_void_p(st))
         _lib.check_launch(rc)
         ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
-        return BatchResult(out, out_off_t, out_len_t, status_t, consumed_t, ms)
+        return BatchResult(out, out_off_t, out_len_t, status_t, consumed_t, ms, (data, in_off_t, in_len_t, out_cap_t, dict_t))
 
     if in_off is None:
         flat, in_off, in_len = pack_streams(data)
@@ -270,6 +274,8 @@ class DecoderBatch:
     def step(self, chunks: Sequence, out_caps):
         lib = _lib.load()
         flat, in_off, in_len = pack_streams(chunks)
+        # one call looks at 2^28 bytes per object at most (32-bit bit counters) and reports what it consumed
+        in_len = np.minimum(in_len, np.uint32(1 << 28))
         out_cap = np.ascontiguousarray(np.broadcast_to(np.asarray(out_caps, dtype=np.uint32), (self.n,)))
         out_off, total = _slab_offsets(out_cap)
         out = np.zeros(total + 1, dtype=np.uint8)

@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import TampAmdConf
 
 CHUNK_SIZE = 1 << 20  # tamp/_c_common.pyx:4
+MAX_STEP_INPUT = 1 << 28  # compressed bytes offered to one decoder call (the kernels' bit counters are 32 bits wide)
 
 
 def _error_lookup():
@@ -212,8 +213,8 @@ class Decompressor:
     def _step(self, room: int):
         """One tamp_decompressor_decompress call: offer the pending input and `room` bytes of output."""
         lib = _lib.load()
-        n = len(self._pending)
-        src = np.frombuffer(self._pending, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        n = min(len(self._pending), MAX_STEP_INPUT)  # one call counts bits in 32-bit registers: offer a bounded piece
+        src = np.frombuffer(self._pending, dtype=np.uint8, count=n) if n else np.zeros(1, np.uint8)
         out = np.empty(max(room, 1), dtype=np.uint8)
         zero = np.zeros(1, dtype=np.uint64)
         in_len, out_cap = np.array([n], dtype=np.uint32), np.array([room], dtype=np.uint32)
@@ -225,6 +226,7 @@ class Decompressor:
                                               _lib.MEM_HOST, self._device, None)
         _lib.check_launch(rc)
         self._pending = self._pending[int(consumed[0]) :]
+        self._progress = int(consumed[0]) > 0
         return int(status[0]), out[: int(out_len[0])]
 
     def readinto(self, buf: bytearray) -> int:  # tamp/_c_decompressor.pyx:77-129
@@ -235,6 +237,8 @@ class Decompressor:
             pos += len(out)
             size -= len(out)
             if res == _lib.INPUT_EXHAUSTED:
+                if self._pending and self._progress:
+                    continue  # a bounded piece was consumed, the rest of what is buffered comes next
                 chunk = self.f.read(CHUNK_SIZE)
                 if not chunk:
                     break

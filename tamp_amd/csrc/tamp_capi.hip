@@ -564,6 +564,11 @@ struct HostBatch {
 struct HostChunk {
     size_t i0, i1;
     uint64_t in_lo, in_hi, out_lo, out_hi;
+    // Output slabs tile [out_lo, out_hi) exactly, in stream order: the copy-back may be ONE transfer of the whole
+    // extent (bytes of a slab behind out_len[i] are unspecified afterwards, include/tamp_amd.h).  Otherwise -- gaps
+    // between slabs, permuted or overlapping extents -- only the out_len[i] bytes of each stream are copied, so
+    // nothing outside the produced bytes is ever written in the caller's buffer.
+    bool out_packed;
 };
 
 // Consecutive streams: a chunk closes once it holds `min_streams` streams and `min_bytes` of data (the larger of its
@@ -580,7 +585,7 @@ void plan_host_chunks(const HostBatch& b, size_t min_streams, uint64_t min_bytes
         in_min = std::min(in_min, b.in_off[i]), out_min = std::min(out_min, b.out_off[i]);
     }
     if (!ordered) {
-        chunks.push_back({0, b.n, in_min, in_max, out_min, out_max});
+        chunks.push_back({0, b.n, in_min, in_max, out_min, out_max, false});
         return;
     }
     size_t i0 = 0;
@@ -593,15 +598,19 @@ void plan_host_chunks(const HostBatch& b, size_t min_streams, uint64_t min_bytes
                                            b.out_off[i1] + b.out_cap[i1] - b.out_off[i0]);
             if ((i1 - i0 >= min_streams && have >= min_bytes) || with > max_bytes) break;
         }
+        bool packed = true;
+        for (size_t i = i0 + 1; i < i1 && packed; i++) packed = b.out_off[i] == b.out_off[i - 1] + b.out_cap[i - 1];
         chunks.push_back({i0, i1, b.in_off[i0], b.in_off[i1 - 1] + b.in_len[i1 - 1], b.out_off[i0],
-                          b.out_off[i1 - 1] + b.out_cap[i1 - 1]});
+                          b.out_off[i1 - 1] + b.out_cap[i1 - 1], packed});
         i0 = i1;
     }
     // a short last chunk is a badly filled launch: give it to its neighbour
     if (chunks.size() >= 2 && chunks.back().i1 - chunks.back().i0 < min_streams / 2) {
         const HostChunk last = chunks.back();
         chunks.pop_back();
-        chunks.back().i1 = last.i1, chunks.back().in_hi = last.in_hi, chunks.back().out_hi = last.out_hi;
+        HostChunk& prev = chunks.back();
+        prev.out_packed = prev.out_packed && last.out_packed && b.out_off[last.i0] == prev.out_hi;
+        prev.i1 = last.i1, prev.in_hi = last.in_hi, prev.out_hi = last.out_hi;
     }
 }
 
@@ -674,12 +683,26 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
         const HostSlot s = slot_of(j, ch);
         const size_t cnt = ch.i1 - ch.i0;
         hipStream_t st = P.s[j];
-        if (ch.out_hi > ch.out_lo)
+        if (ch.out_packed && ch.out_hi > ch.out_lo)
             HIP_OK(hipMemcpyAsync(b.out + ch.out_lo, P.out[j].p, ch.out_hi - ch.out_lo, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(b.out_len + ch.i0, s.out_len, cnt * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(b.status + ch.i0, s.status, cnt, hipMemcpyDeviceToHost, st));
         if (b.in_consumed) HIP_OK(hipMemcpyAsync(b.in_consumed + ch.i0, s.in_consumed, cnt * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
+        if (!ch.out_packed) {
+            // exactly the produced bytes of every stream, runs of touching full slabs merged into one transfer
+            const uint8_t* dev_out = static_cast<const uint8_t*>(P.out[j].p);
+            size_t i = ch.i0;
+            while (i < ch.i1) {
+                const uint64_t lo = b.out_off[i];
+                uint64_t hi = lo + b.out_len[i];
+                size_t k = i + 1;
+                while (k < ch.i1 && b.out_len[k - 1] == b.out_cap[k - 1] && b.out_off[k] == hi) hi += b.out_len[k], k++;
+                if (hi > lo) HIP_OK(hipMemcpyAsync(b.out + lo, dev_out + (lo - ch.out_lo), hi - lo, hipMemcpyDeviceToHost, st));
+                i = k;
+            }
+            HIP_OK(hipStreamSynchronize(st));
+        }
         return TAMP_OK;
     };
     if (chunks.size() == 1) {

@@ -26,7 +26,14 @@ enum : int8_t {
     kExcessBits = -2,
     kInvalidConf = -3,
     kOob = -4,
+    kBadArgument = -21,  // TAMP_AMD_BAD_ARGUMENT (include/tamp_amd.h)
 };
+
+// The decoders count input in BITS in 32-bit registers: one call takes less than 2^29 bytes per stream.  The one-shot
+// batch call reports longer streams as kBadArgument; the resumable call offers itself kMaxDecodeCall bytes and reports
+// them consumed (the caller offers the rest again, as after any TAMP_INPUT_EXHAUSTED).
+constexpr uint32_t kMaxDecodeIn = (1u << 29) - 1;
+constexpr uint32_t kMaxDecodeCall = 1u << 28;
 
 // Match-length prefix code: code without the leading 0 flag, length including it.
 __device__ __constant__ uint8_t d_code[15] = {0x00, 0x03, 0x08, 0x0b, 0x14, 0x24, 0x26, 0x2b,

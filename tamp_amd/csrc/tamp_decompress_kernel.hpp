@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
         };
 
         do {  // single pass; `break` = finished with `res`
+            if (n > kMaxDecodeIn) { res = kBadArgument; break; }  // 32-bit bit counters (tamp_common.hpp)
             if (a.max_wbits < 8 || a.max_wbits > 15) { res = kInvalidConf; break; }  // decompressor.c:336
             // ---- header, decompressor.c:276-297 ----
             if (n == 0) break;

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) tamp_decompress_resume_kernel(ResumeArgs 
         const uint32_t bits_max = s3 >> 24;
 
         const uint8_t* const in = a.in + a.in_off[s];
-        const uint32_t n = a.in_len[s];
+        // (32-bit bit counters: one call looks at kMaxDecodeCall bytes at most and reports what it consumed)
+        const uint32_t n = a.in_len[s] < kMaxDecodeCall ? a.in_len[s] : kMaxDecodeCall;
         uint8_t* const out = a.out + a.out_off[s];
         const uint32_t cap = a.out_cap[s];
         uint32_t op = 0, flushed = 0, ip_ref = 0;

@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(256) tamp_decompress_wave_kernel(DecompressArg
         };
 
         do {
+            if (n > kMaxDecodeIn) { res = kBadArgument; break; }  // 32-bit bit counters (tamp_common.hpp)
             if (a.max_wbits < 8 || a.max_wbits > 15) { res = kInvalidConf; break; }
             if (n == 0) break;
             fetch();

@@ -69,3 +69,79 @@ def csr_for_fixed(n_streams: int, stream_len: int):
     in_off = np.arange(n_streams, dtype=np.uint64) * np.uint64(stream_len)
     in_len = np.full(n_streams, stream_len, dtype=np.uint32)
     return in_off, in_len
+
+
+# ---- real inputs: files cut into independent streams (host-side data preparation only) ----------------------
+
+#: Real-text stand-ins that exist in this image (and on the GPU box) while the metric's own corpus, enwik8, does not
+#: (no network): documentation / licence prose and Python sources.  name -> glob patterns, read in sorted order.
+REAL_TEXT_SOURCES = {
+    "prose": ["/opt/skills/guides/*.md", "{repo}/*.md", "/usr/share/common-licenses/*", "/usr/share/doc/*/copyright"],
+    "python": ["/usr/lib/python3.10/*.py", "/usr/lib/python3.10/*/*.py"],
+}
+
+#: SHA-256 of the reference C's output for the whole enwik8 file as ONE stream, window=10 literal=8, no lazy matching
+#: (/root/reference/tests/test_dataset_regression.py:38-43): (v1 format, extended format); sizes from README.md:266.
+ENWIK8_PINS = {
+    "len": 100_000_000,
+    "v1_sha256": "02e05af059a0040d641988075cf1dfc479a084f9a34b5c8a348354211c5fa038",
+    "extended_sha256": "d9d804c91b4dc5e81856db074760037040421cfa84e1ea211e16dde8c295ce6d",
+    "v1_size": 51_635_633,
+    "extended_size": 51_016_917,
+    "first_100k_v1_size": 50_841,  # README.md:336
+}
+
+
+def gather_files(patterns, max_bytes: int) -> bytes:
+    """Concatenation of the files matching ``patterns`` (sorted per pattern), cut at ``max_bytes``."""
+    import glob
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = bytearray()
+    for pat in patterns:
+        for f in sorted(glob.glob(pat.format(repo=repo))):
+            try:
+                with open(f, "rb") as fh:
+                    buf += fh.read()
+            except OSError:
+                continue
+            if len(buf) >= max_bytes:
+                return bytes(buf[:max_bytes])
+    return bytes(buf)
+
+
+def real_text(name: str, max_bytes: int = 64 << 20) -> bytes:
+    """One of REAL_TEXT_SOURCES as a byte string (possibly empty when nothing matches on this machine)."""
+    return gather_files(REAL_TEXT_SOURCES[name], max_bytes)
+
+
+def split_fixed(blob, chunk: int = 4096, keep_tail: bool = True):
+    """A byte string as independent streams of ``chunk`` bytes: (flat uint8, in_off uint64[n], in_len uint32[n]).
+
+    BASELINE configs[2] ("enwik8 split into independent 4 KiB streams"): the last, shorter piece is KEPT as a short
+    stream (100,000,000 B -> 24,414 streams of 4096 B + one of 576 B) so that every input byte is compressed;
+    ``keep_tail=False`` drops it.
+    """
+    flat = np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob.reshape(-1)
+    total = int(flat.size)
+    n_full = total // chunk
+    tail = total - n_full * chunk
+    n = n_full + (1 if (tail and keep_tail) else 0)
+    in_off = np.arange(n, dtype=np.uint64) * np.uint64(chunk)
+    in_len = np.full(n, chunk, dtype=np.uint32)
+    if tail and keep_tail:
+        in_len[-1] = tail
+    else:
+        flat = flat[: n_full * chunk]
+    return flat, in_off, in_len
+
+
+def tile_rows(blob, n_streams: int, chunk: int = 4096) -> np.ndarray:
+    """``n_streams`` rows of ``chunk`` bytes cut from ``blob``, repeating it when it is shorter (throughput runs)."""
+    flat = np.frombuffer(bytes(blob), dtype=np.uint8)
+    k = flat.size // chunk
+    if k == 0:
+        raise ValueError("corpus shorter than one chunk")
+    rows = flat[: k * chunk].reshape(k, chunk)
+    reps = (n_streams + k - 1) // k
+    return np.ascontiguousarray(np.tile(rows, (reps, 1))[:n_streams])

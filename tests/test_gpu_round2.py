@@ -1,0 +1,350 @@
+"""GPU tier (-m gpu), round 2: real text, the metric's own workload shape, full-size BASELINE configs, regression
+fixtures and bounded randomised runs -- everything through the C ABI, checked against the reference C (oracle/_ref, when
+its prebuilt library travelled to the box) or this repo's restatement of it (oracle/), bit for bit.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from conftest import ROOT, load_golden, unb64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import tamp_amd
+    from tamp_amd import _lib
+
+    lib = _lib.load()
+    assert lib.tamp_amd_device_count() >= 1, "no HIP device visible"
+    return tamp_amd
+
+
+@pytest.fixture(scope="module")
+def checker():
+    """The reference C itself where its prebuilt library is present, else the restatement."""
+    from oracle.checker import Oracle, Ref
+
+    return Ref() if Ref.available() else Oracle()
+
+
+def _streams_of(res, n):
+    olen = np.asarray(res.out_len.cpu() if hasattr(res.out_len, "cpu") else res.out_len)
+    ooff = np.asarray(res.out_off.cpu() if hasattr(res.out_off, "cpu") else res.out_off)
+    out = res.out.cpu().numpy() if hasattr(res.out, "cpu") else res.out
+    return [out[int(ooff[i]) : int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# configs[2] shape on real text: a corpus cut into independent 4 KiB streams, both formats, both kernel builds
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("corpus", ["prose", "python"])
+def test_real_text_4k_chunks_match_reference(ta, checker, corpus):
+    from tamp_amd import workloads as wl
+
+    blob = wl.real_text(corpus, 6 << 20)
+    if len(blob) < 64 * 4096:
+        pytest.skip(f"no {corpus} corpus on this machine")
+    # every stream of the first 2 MiB, then every fifth chunk of the rest: ~750 streams, the short tail included
+    head, rest = blob[: (2 << 20) + 777], blob[(2 << 20) + 777 :]
+    flat, off, ln = wl.split_fixed(head, 4096, keep_tail=True)
+    assert ln[-1] == 777 and len(ln) == 513
+    k = len(rest) // 4096
+    extra = np.frombuffer(rest[: k * 4096], dtype=np.uint8).reshape(k, 4096)[::5]
+    flat = np.concatenate([flat, extra.reshape(-1)])
+    off = np.concatenate([off, off[-1] + np.uint64(777) + np.arange(len(extra), dtype=np.uint64) * np.uint64(4096)])
+    ln = np.concatenate([ln, np.full(len(extra), 4096, dtype=np.uint32)])
+    n = len(ln)
+    for ext in (True, False):
+        want = checker.compress_batch(flat, off, ln, window=10, literal=8, extended=ext, threads=8)
+        for run_aware in (None, False, True):
+            got = ta.compress_batch(flat, off, ln, window=10, literal=8, extended=ext, max_in_len=4096, run_aware=run_aware)
+            assert (np.asarray(got.status) == 0).all()
+            gs = _streams_of(got, n)
+            for i in range(n):
+                assert gs[i] == want.stream(i), (corpus, ext, run_aware, i)
+        # and back: decode what the reference produced
+        back = ta.decompress_batch([want.stream(i) for i in range(n)], out_cap=4096)
+        assert (np.asarray(back.status) == 2).all()
+        bs = _streams_of(back, n)
+        for i in range(n):
+            assert bs[i] == flat[int(off[i]) : int(off[i]) + int(ln[i])].tobytes(), (corpus, ext, i)
+
+
+def test_real_text_one_long_stream_and_other_windows(ta, checker):
+    """configs[0] with a real-text stand-in: the first 64 KiB (and 300 KB) of prose as ONE stream, both formats, lazy
+    matching too; other windows / literal sizes on 4 KiB chunks."""
+    from tamp_amd import workloads as wl
+
+    blob = wl.real_text("prose", 1 << 20)
+    if len(blob) < 300_000:
+        pytest.skip("no prose corpus on this machine")
+    for size in (65536, 300_000):
+        data = np.frombuffer(blob[:size], dtype=np.uint8)
+        off, ln = np.zeros(1, np.uint64), np.array([size], np.uint32)
+        for ext in (True, False):
+            for lazy in (False, True):
+                want = checker.compress_batch(data, off, ln, window=10, literal=8, extended=ext, lazy=lazy)
+                got = ta.compress_batch(data, off, ln, window=10, literal=8, extended=ext, lazy_matching=lazy)
+                assert int(got.status[0]) == 0 and _streams_of(got, 1)[0] == want.stream(0), (size, ext, lazy)
+    rows = wl.tile_rows(blob[:400 * 4096], 400)
+    off, ln = wl.csr_for_fixed(400, 4096)
+    for window, literal in ((8, 8), (9, 8), (11, 8), (12, 8), (15, 8), (10, 7)):
+        flat = (rows & 0x7F if literal == 7 else rows).reshape(-1)
+        for ext in (True, False):
+            want = checker.compress_batch(flat, off, ln, window=window, literal=literal, extended=ext, threads=8)
+            got = ta.compress_batch(flat, off, ln, window=window, literal=literal, extended=ext, max_in_len=4096)
+            gs = _streams_of(got, 400)
+            for i in range(400):
+                assert gs[i] == want.stream(i) and int(got.status[i]) == int(want.status[i]), (window, literal, ext, i)
+
+
+def test_corpus_hook_of_bench(ta, tmp_path):
+    """bench.py --corpus (configs[2]): any file is cut into 4 KiB streams, every stream checked against the reference,
+    and the whole-file pins are only claimed for a file of enwik8's size."""
+    from tamp_amd import workloads as wl
+
+    blob = wl.real_text("prose", 3 << 20)
+    if len(blob) < (1 << 20):
+        pytest.skip("no prose corpus on this machine")
+    p = tmp_path / "corpus.txt"
+    p.write_bytes(blob[: (1 << 20) + 123])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--corpus", str(p), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["streams_total"] == 257 and line["scaling"] == "strong" and line["data"].startswith("real: corpus.txt")
+    assert line["cpu_baseline"]["parity"].startswith("bit-exact, 257 streams")
+    assert line["corpus_pins"]["checked"] is False
+
+
+# --------------------------------------------------------------------------------------------------------------
+# multi-GPU launch path of bench.py on a one-GPU box: shards of one device, no RCCL
+# --------------------------------------------------------------------------------------------------------------
+def test_bench_gpus_2_runs_as_invoked_on_one_device(ta):
+    env = dict(os.environ, TAMP_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--streams", "4096", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["streams_total"] == 8192 and line["config"]["all_streams_ok"]
+    assert "nccl" not in line["config"]["parallelism"] and line["value"] > 0
+
+
+def test_two_shards_same_code_as_bench_match_oracle(ta, oracle):
+    """The N=2 path of bench.py (one Shard per device, its own hipStream, asynchronous launches) on two shards of one
+    device: bytes of every stream against the oracle, shard 1 generated from its own first_index."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from tamp_amd import workloads as wl
+
+    n, slen = 600, 4096
+    shards = []
+    for r in range(2):
+        rows = wl.synth_text(n, slen, first_index=r * n)
+        off, ln = wl.csr_for_fixed(n, slen)
+        sh = bench.Shard(torch, r, torch.device("cuda", 0), rows.reshape(-1), off, ln, slen, dict(window=10, literal=8, extended=True))
+        sh.rows = rows
+        shards.append(sh)
+    res = [sh.launch(record=True) for sh in shards]  # both in flight before either is waited for
+    for sh in shards:
+        sh.sync()
+    assert shards[0].stream.cuda_stream != shards[1].stream.cuda_stream
+    for sh, r in zip(shards, res):
+        off, ln = wl.csr_for_fixed(n, slen)
+        want = oracle.compress_batch(sh.rows.reshape(-1), off, ln, window=10, literal=8, extended=True, threads=8)
+        gs = _streams_of(r, n)
+        for i in range(n):
+            assert gs[i] == want.stream(i), (sh.index, i)
+        assert sh.events[0][0].elapsed_time(sh.events[0][1]) > 0
+
+
+# --------------------------------------------------------------------------------------------------------------
+# host-memory copy-back: nothing but produced bytes is written when the slabs do not tile the output buffer
+# --------------------------------------------------------------------------------------------------------------
+def test_host_copy_back_touches_only_produced_bytes(ta, oracle, monkeypatch):
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+    n, slen = 300, 1500
+    rows = wl.synth_text(n, slen)
+    off, ln = wl.csr_for_fixed(n, slen)
+    cap1 = ta.compress_bound(slen, 8)
+    want = oracle.compress_batch(rows.reshape(-1), off, ln, window=10, literal=8, extended=True, threads=4)
+    conf = _lib.TampAmdConf(window=10, literal=8, extended=1)
+    monkeypatch.setenv("TAMP_AMD_HOST_CHUNK_STREAMS", "64")
+    monkeypatch.setenv("TAMP_AMD_HOST_CHUNK_MB", "1")
+    stride = cap1 + 40  # a gap of 40 bytes behind every slab
+    for layout in ("gaps", "permuted"):
+        order = np.arange(n) if layout == "gaps" else np.random.default_rng(5).permutation(n)
+        out_off = (order.astype(np.uint64) * np.uint64(stride)).astype(np.uint64)
+        cap = np.full(n, cap1, dtype=np.uint32)
+        out = np.full(n * stride + 8, 0xEE, dtype=np.uint8)
+        out_len = np.zeros(n, np.uint32)
+        status = np.zeros(n, np.int8)
+        for fan in ("0", "3"):  # single device path, then TAMP_AMD_ALL_DEVICES with three shards on the one device
+            out[:] = 0xEE
+            monkeypatch.setenv("TAMP_AMD_FANOUT", fan)
+            p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            rc = lib.tamp_batch_compress(C.byref(conf), None, p(rows), p(off), p(ln), p(out), p(out_off), p(cap), p(out_len),
+                                         p(status), n, slen, _lib.MEM_HOST, -1 if fan != "0" else 0, None)
+            assert rc == 0 and (status == 0).all()
+            touched = np.zeros(out.size, dtype=bool)
+            for i in range(n):
+                o, k = int(out_off[i]), int(out_len[i])
+                assert out[o : o + k].tobytes() == want.stream(i), (layout, fan, i)
+                touched[o : o + k] = True
+            assert (out[~touched] == 0xEE).all(), (layout, fan, "bytes outside the produced output were written")
+
+
+def test_decoder_rejects_streams_the_bit_counters_cannot_hold(ta):
+    """in_len >= 2^29: the one-shot batch decoders report TAMP_AMD_BAD_ARGUMENT for that stream and produce nothing; the
+    neighbour in the same batch decodes normally."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    good = ta.compress(b"foo foo foo")
+    big = 1 << 29
+    data = torch.zeros(big + 64, dtype=torch.uint8, device=dev)
+    data[big : big + len(good)] = torch.frombuffer(bytearray(good), dtype=torch.uint8).to(dev)
+    in_off = torch.tensor([0, big], dtype=torch.int64, device=dev)
+    in_len = torch.tensor([big, len(good)], dtype=torch.int32, device=dev)
+    for mode in ("wave", "lane", "global"):
+        os.environ["TAMP_AMD_DECODER"] = mode
+        try:
+            r = ta.decompress_batch(data, in_off, in_len.view(torch.int32), out_cap=64)
+        finally:
+            del os.environ["TAMP_AMD_DECODER"]
+        st = r.status.cpu().numpy()
+        assert int(st[0]) == -21 and int(r.out_len[0]) == 0 and int(r.in_consumed[0]) == 0, mode
+        assert int(st[1]) == 2 and r.stream(1) == b"foo foo foo", mode
+
+
+# --------------------------------------------------------------------------------------------------------------
+# regression fixtures and bounded randomised differential runs (driver-observed, not prose)
+# --------------------------------------------------------------------------------------------------------------
+def test_fuzz_regression_fixtures(ta):
+    for c in load_golden("fuzz_regressions.json")["cases"]:
+        data = unb64(c["input"])
+        for run_aware in (None, False, True):
+            got = ta.compress_batch([data], run_aware=run_aware, **c["conf"])
+            assert int(got.status[0]) == c["status"] and got.stream(0) == unb64(c["expected"]), (c["name"], run_aware)
+        back = ta.decompress_batch([unb64(c["expected"])], out_cap=len(data) + 8)
+        assert int(back.status[0]) == 2 and back.stream(0) == data, c["name"]
+
+
+@pytest.mark.parametrize("tool,seconds", [("fuzz_gpu.py", 25), ("fuzz_stream_gpu.py", 15), ("fuzz_resume_gpu.py", 15),
+                                          ("fuzz_encoder_resume_gpu.py", 15)])
+def test_bounded_randomised_differential(ta, tool, seconds):
+    """tools/fuzz_*.py for a bounded budget each: compress (all modes, both builds) and decompress (all three decoders),
+    streaming scripts, decoder objects, encoder objects -- against the oracle / live reference objects."""
+    if tool == "fuzz_encoder_resume_gpu.py":
+        from oracle.checker import Ref
+
+        if not Ref.available():
+            pytest.skip("needs the prebuilt reference library (oracle/_ref)")
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, FUZZ_SEED=str(20260929))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seconds)], capture_output=True, text=True,
+                         timeout=seconds * 6 + 240, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "ok" in out.stdout.lower(), out.stdout[-500:]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] and one GPU's share of configs[4] at FULL size: size-independent properties + sampled oracle
+# --------------------------------------------------------------------------------------------------------------
+def test_full_size_config4_decode_one_million_streams(ta, oracle):
+    """configs[3]: 1,048,576 pre-compressed 4 KiB streams, windows 2^8..2^12 interleaved, decoded in ONE call.
+    Properties: every status 2, every length 4096, consumed == stream length, sampled streams equal their text, the
+    compressed sample equals the oracle's bytes, and a checksum of the whole output equals the checksum of the text."""
+    import torch
+
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda", 0)
+    n, L = 1 << 20, 4096
+    per = n // 5 + 1
+    wsel = torch.arange(n, device=dev) % 5 + 8
+    olen = torch.zeros(n, dtype=torch.int64, device=dev)
+    parts = {}
+    for w in range(8, 13):
+        ids = torch.nonzero(wsel == w).flatten()
+        rows = wl.synth_text(len(ids), L, first_index=w * 1000003)
+        off, ln = wl.csr_for_fixed(len(ids), L)
+        r = ta.compress_batch(torch.from_numpy(rows.reshape(-1)).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev),
+                              torch.from_numpy(ln.astype(np.int32)).to(dev), window=w, max_in_len=L)
+        assert bool((r.status == 0).all().item())
+        k = 48  # the compressor's own parity at this window, sampled against the oracle
+        want = oracle.compress_batch(rows[:k].reshape(-1), off[:k], ln[:k], window=w, literal=8, extended=True, threads=8)
+        gs = _streams_of(r, k)
+        assert all(gs[i] == want.stream(i) for i in range(k)), w
+        olen[ids] = r.out_len.to(torch.int64)
+        parts[w] = (ids, rows, r)
+        assert len(ids) <= per
+    in_off = torch.cumsum(olen, 0) - olen
+    slab = torch.empty(int(olen.sum().item()) + 64, dtype=torch.uint8, device=dev)
+    text_sum = 0
+    for w, (ids, rows, r) in parts.items():
+        lens, src, dst = r.out_len.to(torch.int64), r.out_off.to(torch.int64), in_off[ids]
+        rep = torch.repeat_interleave(torch.arange(len(ids), device=dev), lens)
+        within = torch.arange(int(lens.sum().item()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        slab[dst[rep] + within] = r.out[src[rep] + within]
+        del rep, within
+        text_sum += int(rows.astype(np.uint64).sum())
+    cap = torch.full((n,), L, dtype=torch.int32, device=dev)
+    d = ta.decompress_batch(slab, in_off, olen.to(torch.int32), out_cap=cap, timing=True)
+    assert bool((d.status == 2).all().item()) and bool((d.out_len == L).all().item())
+    assert bool((d.in_consumed.to(torch.int64) == olen).all().item())
+    assert int(d.out[: n * L].sum(dtype=torch.int64).item()) == text_sum  # checksum over all 4 GiB
+    for w, (ids, rows, r) in parts.items():
+        step = max(1, len(ids) // 300)
+        sel = ids[::step][:300].tolist()
+        for j, s in enumerate(sel):
+            assert d.out[s * L : (s + 1) * L].cpu().numpy().tobytes() == rows[j * step].tobytes(), (w, s)
+    print(f"\nconfigs[3] full size: {n} streams, {int(olen.sum().item()) / 2**30:.2f} GiB in, 4 GiB out, decode {d.kernel_ms:.2f} ms "
+          f"= {n * L / d.kernel_ms / 1e6:.1f} GB/s out")
+
+
+def test_full_size_config5_one_gpu_share(ta, oracle):
+    """configs[4], one GPU's share at 8 GPUs: 2,097,152 x 256 B telemetry messages, shared custom dictionary, window=8
+    literal=7 extended (header 0x16); three messages carry a byte >= 0x80 -> TAMP_EXCESS_BITS exactly there; the first
+    4,096 equal the oracle's bytes; everything decodes back to the input."""
+    import torch
+
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda", 0)
+    n, L = 1 << 21, 256
+    dct = wl.telemetry_dictionary(bytes(ta.initialize_dictionary(256, literal=7)))
+    rows = wl.telemetry(n, L).copy()
+    bad_ids = [5, n // 3, n - 2]
+    for b in bad_ids:
+        rows[b, 40] = 0xC3
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off_t = torch.arange(n, dtype=torch.int64, device=dev) * L
+    len_t = torch.full((n,), L, dtype=torch.int32, device=dev)
+    r = ta.compress_batch(data, off_t, len_t, window=8, literal=7, dictionary=dct, max_in_len=L, timing=True)
+    st = r.status.cpu().numpy()
+    assert np.nonzero(st != 0)[0].tolist() == sorted(bad_ids) and all(int(st[b]) == -2 for b in bad_ids)
+    assert int(r.out[0]) == 0x16
+    off, ln = wl.csr_for_fixed(4096, L)
+    want = oracle.compress_batch(rows[:4096].reshape(-1), off, ln, window=8, literal=7, dictionary=dct, threads=8)
+    gs = _streams_of(r, 4096)
+    assert all(gs[i] == want.stream(i) and int(st[i]) == int(want.status[i]) for i in range(4096))
+    back = ta.decompress_batch(r.out, r.out_off, r.out_len, out_cap=L, dictionary=dct, timing=True)
+    good = torch.ones(n, dtype=torch.bool, device=dev)
+    good[torch.tensor(bad_ids, device=dev)] = False
+    assert bool((back.status[good] == 2).all().item()) and bool((back.out_len[good] == L).all().item())
+    assert bool((back.out[: n * L].view(n, L)[good] == data.view(n, L)[good]).all().item())
+    print(f"\nconfigs[4] share: {n} x {L} B compress {r.kernel_ms:.2f} ms = {n * L / r.kernel_ms / 1e6:.1f} GB/s in, "
+          f"decode {back.kernel_ms:.2f} ms = {n * L / back.kernel_ms / 1e6:.1f} GB/s out")

@@ -119,5 +119,46 @@ def test_bench_reads_committed_pmc_summaries():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    t = mod.pmc_traffic_bytes()
+    t, source = mod.pmc_traffic_bytes()
     assert t is not None and 3e8 < t < 1e11  # at least the 268 MB of input; not absurd
+    assert "profiles/" in source
+
+
+def test_corpus_split_and_sharding_tile_the_file():
+    """configs[2] host logic: a file cut into 4 KiB streams (short tail kept) and the streams cut into contiguous ranges per
+    GPU cover every byte exactly once, for every world size bench.py is launched with."""
+    from tamp_amd import workloads as wl
+
+    blob = bytes(range(256)) * 391 + b"tail!"  # 100,101 bytes: 24 full chunks + one of 1,797
+    flat, off, ln = wl.split_fixed(blob, 4096)
+    assert len(ln) == 25 and int(ln[-1]) == len(blob) - 24 * 4096 and flat.tobytes() == blob
+    assert (off == np.arange(25, dtype=np.uint64) * 4096).all()
+    f2, o2, l2 = wl.split_fixed(blob, 4096, keep_tail=False)
+    assert len(l2) == 24 and f2.size == 24 * 4096
+    for world in (1, 2, 4, 8, 32):
+        ranges = sharding.partition_streams(ln, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == 25
+        got = b""
+        for (b, e), nxt in zip(ranges, ranges[1:] + [(25, 25)]):
+            assert e == nxt[0]
+            if e > b:
+                lo, hi = int(off[b]), int(off[e - 1] + ln[e - 1])
+                got += flat[lo:hi].tobytes()
+        assert got == blob
+    rows = wl.tile_rows(blob, 60, 4096)
+    assert rows.shape == (60, 4096) and rows[24].tobytes() == blob[:4096] and rows[59].tobytes() == blob[11 * 4096 : 12 * 4096]
+    assert set(wl.ENWIK8_PINS) >= {"len", "v1_sha256", "extended_sha256", "v1_size", "extended_size"}
+
+
+def test_bench_host_helpers():
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    threads, affinity, quota = bench.host_threads()
+    assert 1 <= threads <= affinity and (quota is None or threads <= quota)
+    assert isinstance(bench.cpu_model(), str)
+    traffic, src = bench.pmc_traffic_bytes()
+    assert traffic is None or traffic > 0
