@@ -46,10 +46,22 @@ __host__ __device__ inline int min_pattern_size(int window, int literal) {
     return 2 + (window > 10 + 2 * (literal - 5));
 }
 
+// gfx950 LDS serves misaligned ds_read_b32 / _b128 in hardware (the compiler emits them for align-1 types); a
+// misaligned access costs the LDS pipe extra passes, so the hot bucket scan keeps aligned dwords + v_alignbyte.
+struct __attribute__((packed, aligned(1))) LdsU32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) LdsU128 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint32_t lds_u32_hw(const uint8_t* base, uint32_t off) {
+    return reinterpret_cast<const LdsU32*>(base + off)->v;
+}
+
 // 4 bytes at an arbitrary LDS byte offset: two aligned dwords funnel-shifted by the byte phase.
 __device__ __forceinline__ uint32_t lds_u32_unaligned(const uint8_t* base, uint32_t off) {
+#ifdef TAMP_HWUA_ALL
+    return lds_u32_hw(base, off);
+#else
     const uint32_t* w = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
     return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3u);
+#endif
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {

@@ -872,6 +872,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         TAMP_FINE(f0);
                         if constexpr (!LAZY) {
                             const uint32_t Ws = WSCAN ? WSCAN : W;  // (see the template parameter)
+#ifdef TAMP_PROF
+                            // instruction-count experiments: run the (idempotent) loop twice, count the difference
+                            const uint32_t sl0 = sl;
+                            uint32_t n16_first = 0;
+                            for (uint32_t rep = 0; rep < ((a.dbg & 0x100u) ? 2u : 1u); rep++) {
+                            if (rep) { n16_first = n16; sl = sl0; e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl]; }
+#endif
                             while (sl < s_hi) {
 #ifdef TAMP_PROF
                                 niter++;
@@ -888,11 +895,17 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                 // W - i = 1 rejects it below.)
                                 if (d <= Ws - 2 && (x & ((1u << kRemBits) - 1)) == 0) {
                                     const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
-                                    if (t < 16) {
-                                        wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
+                                    uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
+                                    if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                                    // The candidate's first t bytes lie in front of the newest window byte, where the
+                                    // buffer IS the ring: a common prefix shorter than t is exact whatever follows.  Only
+                                    // a candidate that agrees all the way to the newest byte (periodic input: rare) goes
+                                    // on with the OLDEST window bytes and is resolved after the loop.  (Its payload and
+                                    // the 16-byte compare look at buffer bytes behind the newest one there, but any
+                                    // length they report is then >= t.)
+                                    if (t < 16 && len >= t) {
+                                        wrapmask |= 1u << t;
                                     } else {
-                                        uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
-                                        if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
                                         if constexpr (RUNS) n16 += len >> 4;
                                         // key = length << 16 | (W - index): longest, then lowest index.  W - i is also
                                         // the limit "may not run past index W-1"; a clipped length of 1 (index W-1)
@@ -902,6 +915,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     }
                                 }
                             }
+#ifdef TAMP_PROF
+                            if (rep) n16 = n16_first;
+                            }
+#endif
                         } else
                         while (sl < s_hi) {
 #ifdef TAMP_PROF
@@ -947,6 +964,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         // not in the index at all: test its first byte here.
                         // (a match there needs the oldest byte to equal the pattern's second byte as well)
                         if (ebuf[q + W - 1] == (P[0] & 0xFFu) && ebuf[q] == ((P[0] >> 8) & 0xFFu)) wrapmask |= 2u;
+#ifdef TAMP_PROF
+                        const uint32_t wrapmask0 = wrapmask;
+                        for (uint32_t rep = 0; rep < ((a.dbg & 0x200u) ? 2u : 1u); rep++) {
+                        wrapmask = wrapmask0;
+#endif
                         while (wrapmask) {
                             const uint32_t t = (uint32_t)__builtin_ctz(wrapmask);
                             wrapmask &= wrapmask - 1;
@@ -959,6 +981,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const uint32_t k = (len << 16) | (W - i);
                             if (len >= 2 && k > key) key = k;
                         }
+#ifdef TAMP_PROF
+                        }
+#endif
                         if constexpr (RUNS) {
                             // Extended matches (compressor.c:437-468, 636-644): a first match longer than min+11 starts
                             // a continuation that ends at "the candidate at or above the first match's index with the

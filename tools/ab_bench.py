@@ -14,7 +14,7 @@ dev = torch.device('cuda:0')
 data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
 cap = torch.full((n,), 4609, dtype=torch.int32, device=dev)
 out = []
-for ext in (1, 0):
+for ext in ((1,) if os.environ.get('AB_ONLY_EXT') == '1' else (0,) if os.environ.get('AB_ONLY_EXT') == '0' else (1, 0)):
     ms = []
     for it in range(6):
         r = tamp_amd.compress_batch(data, off_t, len_t, extended=bool(ext), max_in_len=4096, out_cap=cap, timing=True)
