@@ -557,6 +557,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint32_t* const jc32 = reinterpret_cast<uint32_t*>(smem + L.ent + L.jump);      // default parse: jump | count << 16
     uint8_t* const vstep = smem + L.ent + L.vstep;  // lazy builds: transition of every (position, state), same alias
     uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
+    // RUNS builds: bytes consumed by the tokens the match phase settles completely (short RLE runs, extended matches
+    // without a rival): second half of the cursor space, behind the 256 explicit pieces of `stok`; written after the
+    // match loops (when `sorted` is dead), read by the jump tables, the walk's token listing and the emitter
+    uint8_t* const xcnt = smem + L.cnt + kSlowCap * 8;
     uint8_t* const blen = smem + L.blen;
     uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
     uint8_t* const blen2 = smem + L.blen2;                                    // only carved when lazy
@@ -1131,6 +1135,67 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 #ifdef TAMP_PROF
                 pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[10] += niter;
 #endif
+                if constexpr (RUNS && PACKED) {
+                    // Tokens of the extended format that need no state machine.  A position is flagged slow when
+                    // poll_extended_handling does more than fall through there (compressor.c:437-525).  Two of those
+                    // cases are decided by the bytes and the match tables alone whenever the walk arrives in the clean
+                    // state "everything consumed has been written" -- the only state in which it consults the tables:
+                    //  * a run of 2..8 bytes equal to the previous byte that ends inside the input: the RLE token of
+                    //    compressor.c:342-359 (or, for runs of 2..6, the ordinary match when that is longer, :490-503);
+                    //    8 bytes at most are written for a run (:352-358), so such a token writes what it consumes;
+                    //  * a first match longer than min+11 without a rival (bit 6, see the match phase): the extended
+                    //    match ends where the common prefix of that window position and the input ends (:297-333,
+                    //    377-415), provided it stays in front of the newest window byte.
+                    // Both become plain steps of xcnt[q] bytes (bit 5 of blen; length field 1 = RLE token) that the
+                    // jump tables chase and the emitter turns into bits, unless the window write would be clipped at the
+                    // ring end (W - window_pos bytes, :355 / :404-410): those, long runs, runs reaching the end of the
+                    // input and matches with rivals stay with the state machine.
+                    if (ext && (kSlowCap * 8 + a_blk) <= kHashBuckets * 2) {
+                        const uint32_t max_ext = minp + 11 + kExtExtraMax;
+                        for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
+                            const uint32_t sv = blen[q];
+                            if (!(sv & 0x80u)) continue;
+                            const uint32_t len = sv & 0x1Fu;
+                            const uint32_t leftq = n - (e_p0 + q);
+                            const uint32_t wpq = (e_wp + q) & mask;  // window_pos when the walk arrives here clean
+                            const uint32_t b4 = lds_u32_unaligned(ebuf, W + q - 1);  // previous byte, then the next three
+                            const uint32_t prev = b4 & 0xFFu, b0 = (b4 >> 8) & 0xFFu, b1 = (b4 >> 16) & 0xFFu;
+                            if (prev == b0) {
+                                if (b1 != b0 || leftq < 2) continue;  // (a single byte at the very end of the input)
+                                // run length from q, looked at up to 9 bytes
+                                const uint32_t rep = b0 * 0x01010101u;
+                                const uint32_t x0 = lds_u32_unaligned(ebuf, W + q + 2) ^ rep, x1 = lds_u32_unaligned(ebuf, W + q + 6) ^ rep;
+                                const uint32_t r = 2u + (x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4u + (x1 ? (uint32_t)__builtin_ctz(x1) >> 3 : 4u));
+                                if (r > kRleWindowMax || r >= leftq || wpq + r > W) continue;
+                                if (r <= 6 && len > r) {  // the pattern wins: an ordinary match step (or an extended match: slow)
+                                    if (len <= minp + 11) blen[q] = (uint8_t)len;
+                                    continue;
+                                }
+                                blen[q] = (uint8_t)(0x20u | 1u);
+                                xcnt[q] = (uint8_t)r;
+                                continue;
+                            }
+                            if (!(sv & 0x40u)) continue;
+                            const uint32_t idx = bidx[q];
+                            const uint32_t off = (idx - wpq) & mask, t0 = W - off;  // candidate = ebuf[q + off ..], t0 bytes in front of the newest one
+                            const uint32_t lim = min(min(W - idx, max_ext), min(leftq, t0));
+                            uint32_t m = 0;
+                            while (m < lim) {
+                                const uint32_t x = lds_u32_unaligned(ebuf, q + off + m) ^ lds_u32_unaligned(ebuf, W + q + m);
+                                if (x) {
+                                    m += (uint32_t)__builtin_ctz(x) >> 3;
+                                    break;
+                                }
+                                m += 4;
+                            }
+                            const uint32_t cnt = min(m, lim);
+                            if (cnt >= t0 || cnt < len || wpq + cnt > W) continue;
+                            blen[q] = (uint8_t)(0x20u | len);
+                            xcnt[q] = (uint8_t)cnt;
+                        }
+                    }
+                    __syncthreads();
+                }
                 for (uint32_t k = 4 + tid; k < 4 + a_blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
                 // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
@@ -1167,7 +1232,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 for (uint32_t b = wave * 64; b < nv; b += (nt >> 6) * 64) {
                     const uint32_t sv = steps[b + lane];  // sentinels (0x80) beyond the last state
                     const bool slowp = (sv & 0x80u) != 0;
-                    const uint32_t stepv = LAZY ? (sv & 0x7Fu) : (sv >= minp ? (sv & 0x1Fu) : 1u);
+                    uint32_t stepv = LAZY ? (sv & 0x7Fu) : (sv >= minp ? (sv & 0x1Fu) : 1u);
+                    if constexpr (RUNS && PACKED) { if (sv & 0x20u) stepv = xcnt[b + lane]; }  // RLE run / extended match settled above
                     // packed: target * 4 (relative target 0..97 as the byte offset ds_bpermute wants) | count << 10 |
                     // finished << 18.  A round is five VALU operations: the count field of the own state is added onto
                     // the state fetched from the target (which brings target, count and the finished bit along; counts
@@ -1210,7 +1276,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         for (uint32_t cleft = LAZY ? (uint32_t)count8[pp] : jc32[pp] >> 16; cleft; cleft--) {
                             toklist[slot++] = (uint16_t)pp;
                             const uint32_t sv = steps[pp];
-                            pp += LAZY ? sv : (sv >= minp ? sv : 1u);
+                            if (RUNS && PACKED && (sv & 0x20u))
+                                pp += xcnt[pp];
+                            else
+                                pp += LAZY ? sv : (sv >= minp ? sv : 1u);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1365,6 +1434,23 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     idx = cached ? (uint32_t)bidx2[pos - 1] : (uint32_t)bidx[pos];
                 } else {
                     len = blen[pos] & 0x1Fu, idx = bidx[pos];
+                    if constexpr (RUNS && PACKED) {
+                        if (blen[pos] & 0x20u) {  // tokens settled by the match phase: xcnt[pos] bytes
+                            const uint32_t cnt = xcnt[pos];
+                            if (len == 1) {  // write_rle_token, compressor.c:342-359: symbol 12, then count - 2 (4 trailing bits)
+                                const uint32_t val = cnt - 2, ci = val >> 4;
+                                const uint32_t hn = tok_nbits(ci) - 1 + 4;
+                                v = ((uint32_t)codetab[kSymRle] << hn) | ((uint32_t)codetab[ci] << 4) | (val & 15u);
+                                nb = tok_nbits(kSymRle) + hn;
+                            } else {  // write_extended_match_token, :377-415: symbol 13, size - min - 12 (3 trailing bits), position
+                                const uint32_t val = cnt - minp - 12, ci = val >> 3;
+                                const uint32_t hn = tok_nbits(ci) - 1 + 3;
+                                v = ((((uint32_t)codetab[kSymExt] << hn) | ((uint32_t)codetab[ci] << 3) | (val & 7u)) << wbits) | idx;
+                                nb = tok_nbits(kSymExt) + hn + wbits;
+                            }
+                            return true;
+                        }
+                    }
                 }
                 if (len < minp) {  // compressor.c:625-632
                     const uint32_t c = ebuf[W + pos];
