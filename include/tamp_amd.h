@@ -48,9 +48,8 @@ typedef struct TampAmdConf {
     uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
     uint8_t lazy_matching;         /* compressor.c:576-619; a bit over half the default mode's speed */
     uint8_t input_hint;            /* TAMP_AMD_HINT_*: which build of the compress kernel parses the batch (same bytes
-                                      either way).  AUTO: host-memory batches are sampled on the host (stream length,
-                                      share of bytes inside runs of 8+ equal bytes); device-memory batches
-                                      take RUNS when max_in_len is 0 or >= 1024, else PLAIN. */
+                                      either way).  AUTO goes by stream length alone: RUNS when max_in_len (given, or
+                                      computed from in_len for host memory) is 0 or >= 1024, else PLAIN. */
     uint8_t reserved;
 } TampAmdConf;
 
@@ -98,12 +97,6 @@ void tamp_window_copy(unsigned char *window, uint16_t *window_pos, uint16_t wind
 /* Worst-case compressed size of an n-byte stream: header byte(s) + every byte a literal
  * (compressor.h flush table / SURVEY.md H7). */
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset);
-
-/* The sampling behind TAMP_AMD_HINT_AUTO, for callers whose batch lives in device memory but who can show the library a
- * few streams on the host: looks at up to 64 of the n_streams streams (first 4 KiB each, HOST pointers) and returns
- * TAMP_AMD_HINT_RUNS or TAMP_AMD_HINT_PLAIN for TampAmdConf.input_hint.  Pure host code, no device needed. */
-uint8_t tamp_amd_input_hint(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, size_t n_streams,
-                            int extended /* TampAmdConf.extended of the batch */);
 
 /* Number of visible HIP devices (0 when there is none), and the library version string. */
 int tamp_amd_device_count(void);

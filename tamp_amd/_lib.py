@@ -25,7 +25,6 @@ SYMBOLS = (
     "tamp_compute_min_pattern_size",
     "tamp_window_copy",
     "tamp_amd_compress_bound",
-    "tamp_amd_input_hint",
     "tamp_amd_device_count",
     "tamp_amd_version",
     "tamp_amd_last_error",
@@ -116,8 +115,6 @@ def load() -> C.CDLL:
     lib.tamp_compute_min_pattern_size.restype = C.c_int8
     lib.tamp_amd_compress_bound.argtypes = [sz, u8, i32]
     lib.tamp_amd_compress_bound.restype = sz
-    lib.tamp_amd_input_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, sz, i32]
-    lib.tamp_amd_input_hint.restype = u8
     lib.tamp_amd_device_count.restype = i32
     lib.tamp_amd_version.restype = C.c_char_p
     lib.tamp_amd_last_error.restype = C.c_char_p

@@ -46,7 +46,7 @@ class BatchResult:
 
 
 def _conf(window, literal, extended, dictionary, dictionary_reset=False, lazy_matching=False, run_aware=None) -> TampAmdConf:
-    # run_aware: None = TAMP_AMD_HINT_AUTO (host batches are sampled by the library), False = PLAIN, True = RUNS
+    # run_aware: None = TAMP_AMD_HINT_AUTO (by stream length), False = PLAIN, True = RUNS
     hint = 0 if run_aware is None else (2 if run_aware else 1)
     return TampAmdConf(window, literal, int(dictionary is not None), int(bool(extended)), int(bool(dictionary_reset)),
                        int(bool(lazy_matching)), hint)
@@ -83,16 +83,6 @@ def _slab_offsets(caps: np.ndarray):
     return offs, int(caps.astype(np.uint64).sum())
 
 
-def input_hint(sample, extended: bool = True) -> bool:
-    """The library's AUTO sampling on a host-side sample (list of bytes-likes): True when the run-aware build of the
-    compress kernel should parse data like this (pass it as ``run_aware=`` for device batches)."""
-    lib = _lib.load()
-    flat, off, ln = pack_streams([bytes(x) for x in sample])
-    if not len(ln):
-        return False
-    return lib.tamp_amd_input_hint(flat.ctypes.data, off.ctypes.data, ln.ctypes.data, len(ln), int(bool(extended))) == 2
-
-
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
                    dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
                    max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False,
@@ -105,8 +95,7 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     of the reference.  ``status[i]`` holds the reference's ``tamp_res`` code for that stream.
     ``run_aware`` picks the kernel build (same bytes either way): True = the run-aware build (long runs listed once,
     most extended matches settled without a search: faster for streams of 1 KiB and more), False = the lean build
-    (faster for short messages), None = the library decides (host batches are sampled; device batches go by
-    ``max_in_len``).
+    (faster for short messages), None = the library decides by stream length (``max_in_len`` >= 1 KiB -> run-aware).
     """
     lib = _lib.load()
     conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching, run_aware)

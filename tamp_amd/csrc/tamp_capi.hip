@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -39,6 +40,9 @@ struct DeviceCtx {
     int cu_count = 0;
     size_t lds_per_block = 0;
     uint8_t* seed_dicts = nullptr;  // 3 x 32 KiB: literal<=5, ==6, >=7
+    uint32_t* work_counters = nullptr;  // persistent-grid builds: one stream counter per launch, handed out round robin
+    std::atomic<uint32_t> next_counter{0};
+    static constexpr uint32_t kCounters = 4096;
     // decoder window slabs, one per HIP stream that ever needed one: launches on one stream are ordered and may share
     // a slab, launches on different streams run concurrently and may not
     struct Slab {
@@ -132,6 +136,7 @@ int get_ctx(int device, DeviceCtx** out) {
         seed_dictionary_host(host.data() + 2 * kSeedTable, kSeedTable, 8);
         HIP_OK(hipMalloc(&c.seed_dicts, 3 * kSeedTable));
         HIP_OK(hipMemcpy(c.seed_dicts, host.data(), 3 * kSeedTable, hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&c.work_counters, DeviceCtx::kCounters * sizeof(uint32_t)));
         c.ready = true;
     }
     *out = &c;
@@ -197,35 +202,6 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     return blk;
 }
 
-// TAMP_AMD_HINT_AUTO for host-memory batches: look at up to 64 streams (first 4 KiB each).  The run-aware build is the
-// faster one for streams of 1 KiB and more (it settles most extended matches without a window search, and lists long
-// runs instead of indexing them byte by byte) -- unless, in the extended format, most of the data sits in runs of 8+
-// bytes: the RLE path owns nearly every position then and the run search is pure overhead (all zeros: 1.7 against
-// 2.3 ms).  Short messages take the lean build (256-byte telemetry: 2.2 against 2.5 ms).
-uint8_t sample_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams, bool extended) {
-    uint64_t bytes = 0, in_runs = 0;
-    const size_t step = n_streams > 64 ? n_streams / 64 : 1;
-    for (size_t i = 0; i < n_streams; i += step) {
-        const uint8_t* p = in + in_off[i];
-        const uint32_t n = std::min<uint32_t>(in_len[i], 4096);
-        bytes += n;
-        for (uint32_t k = 0; k < n;) {
-            uint32_t e = k + 1;
-            while (e < n && p[e] == p[k]) e++;
-            if (e - k >= 8) in_runs += e - k;
-            k = e;
-        }
-    }
-    uint64_t total = 0;
-    for (size_t i = 0; i < n_streams; i += step) total += in_len[i];
-    const uint64_t sampled = (n_streams + step - 1) / step;
-    const bool long_streams = total >= 1024 * sampled;
-    // v1 format: no RLE token takes the runs off the match finder's hands, so the run list pays however much of the
-    // data is runs (all zeros: 20 -> 1.3 ms for 4,096 x 4 KiB)
-    const bool pays = !extended || in_runs * 2 <= bytes;
-    return (long_streams && bytes && pays) ? TAMP_AMD_HINT_RUNS : TAMP_AMD_HINT_PLAIN;
-}
-
 int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
                     const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                     const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, size_t n_streams,
@@ -257,14 +233,15 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     a.n_streams = (uint32_t)n_streams;
     a.prof = g_prof;
+    a.work_counter = nullptr;
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     const uint32_t W = 1u << conf->window;
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
     // run-list build: long runs of one byte leave the bigram index; default parse only
-    // AUTO that reaches this point (device-memory batches; host batches were sampled): the run-aware build for streams of
-    // 1 KiB and more -- it settles most extended matches without a window search and is the faster one on every kind of
-    // text measured, runs or not (config 2: 6.89 against 7.29 ms) -- the lean build for short messages (256-byte
-    // telemetry: 2.2 against 2.5 ms), where its per-epoch run search does not pay
+    // AUTO goes by stream length alone, for host and device batches alike (no look at the data): the run-aware build for
+    // streams of 1 KiB and more -- it settles short RLE runs and most extended matches in the match phase and is the faster
+    // one on every kind of text measured, runs or not (config 2: 6.89 against 7.29 ms) -- the lean build for short
+    // messages (256-byte telemetry: 2.2 against 2.5 ms), where its per-epoch run search does not pay
     bool runlist = conf->input_hint == TAMP_AMD_HINT_RUNS || (conf->input_hint == TAMP_AMD_HINT_AUTO && (max_in_len == 0 || max_in_len >= 1024));
     if (const char* e = getenv("TAMP_AMD_RUNS")) runlist = atoi(e) != 0;  // tuning / tests
     runlist = runlist && !a.lazy;
@@ -289,15 +266,25 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
                                (int)L.total));
     timing_begin(st);
 #ifdef TAMP_STREAM_LOOP
-    const size_t launch_step = n_streams;
+    {   // persistent grid: what the device holds at once, streams handed out by a counter
+        int per_cu = 0;
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), (int)threads, L.total));
+        if (per_cu < 1) per_cu = 1;
+        const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
+        a.work_counter = ctx->work_counters + slot;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
+        a.first_stream = 0;
+        const uint32_t g = (uint32_t)std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, n_streams);
+        hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), L.total, st, a);
+    }
 #else
     const size_t launch_step = grid;
-#endif
     for (size_t first = 0; first < n_streams; first += launch_step) {  // one stream per workgroup
         a.first_stream = (uint32_t)first;
         const uint32_t g = (uint32_t)std::min<size_t>(grid, n_streams - first);
         hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), L.total, st, a);
     }
+#endif
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;
@@ -876,12 +863,6 @@ void tamp_window_copy(unsigned char* window, uint16_t* window_pos, uint16_t wind
     *window_pos = p;
 }
 
-uint8_t tamp_amd_input_hint(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, size_t n_streams,
-                            int extended) {
-    if (!in || !in_off || !in_len || !n_streams) return TAMP_AMD_HINT_PLAIN;
-    return sample_input_hint(in, in_off, in_len, n_streams, extended != 0);
-}
-
 size_t tamp_amd_compress_bound(size_t n, uint8_t literal, int dictionary_reset) {
     return 1 + (dictionary_reset ? 1 : 0) + (n * ((size_t)literal + 1) + 7) / 8;
 }
@@ -976,9 +957,6 @@ int tamp_batch_compress(const TampAmdConf* conf, const uint8_t* dictionary, cons
         for (size_t i = 0; i < n_streams; i++) maxlen = std::max(maxlen, in_len[i]);
         max_in_len = maxlen ? maxlen : 16;
     }
-    TampAmdConf conf_resolved = *conf;
-    if (conf_resolved.input_hint == TAMP_AMD_HINT_AUTO) conf_resolved.input_hint = sample_input_hint(in, in_off, in_len, n_streams, conf->extended != 0);
-    conf = &conf_resolved;
     const HostBatch b = {in, in_off, in_len, out, out_off, out_cap, out_len, status, nullptr, n_streams};
     std::vector<HostChunk> chunks;
     // a chunk fills the device three times over (256 CUs x 6 workgroups = 1,536 streams at once); measured best for
@@ -1295,6 +1273,7 @@ tamp_res compat_encoder_call(TampCompressor* compressor, int op, bool write_toke
 
 // A whole segment on an object that is between segments (ring empty, nothing pending, output bits byte aligned) with
 // ample output room: the batch kernel's segment mode instead of token-by-token parsing.  Same bytes, same state after.
+constexpr size_t kCompatPiece = (size_t)1 << 30;  // input bytes one object-level device call looks at
 bool compat_segment_applies(const TampAmdEncoderState* s, size_t input_size, size_t output_size) {
     if (input_size < 2048 || input_size > 0xFFFFFFFFull) return false;
     if (s->input_size || s->rle_count || s->extended_match_count || s->cached_match_index >= 0) return false;
@@ -1370,14 +1349,25 @@ tamp_res tamp_compressor_poll(TampCompressor* compressor, unsigned char* output,
 tamp_res tamp_compressor_compress_cb(TampCompressor* compressor, unsigned char* output, size_t output_size,
                                      size_t* output_written_size, const unsigned char* input, size_t input_size,
                                      size_t* input_consumed_size, tamp_callback_t callback, void* user_data) {
-    size_t consumed = 0;
-    tamp_res r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS, false, output, output_size, output_written_size,
-                                     input, input_size, &consumed);
+    // One device call takes up to kCompatPiece bytes (32-bit lengths on the device side); longer inputs go piece by
+    // piece on the same object -- the reference's own loop does nothing else (compressor.c:700-719) -- and the progress
+    // callback (common.h:184-210: (input consumed, total input)) fires after every piece.
+    size_t consumed = 0, written = 0;
+    tamp_res r = TAMP_OK;
+    do {
+        const size_t piece = std::min(input_size - consumed, kCompatPiece);
+        size_t c = 0, w = 0;
+        r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS, false, output + written, output_size - written, &w,
+                                input + consumed, piece, &c);
+        consumed += c, written += w;
+        if (r == TAMP_OK && callback) {
+            int cb = callback(user_data, consumed, input_size);
+            if (cb) r = (tamp_res)cb;
+        }
+        if (c < piece) break;  // output room ran out (TAMP_OUTPUT_FULL) or an error: the caller sees how far it got
+    } while (r == TAMP_OK && consumed < input_size);
     if (input_consumed_size) *input_consumed_size = consumed;
-    if (r == TAMP_OK && callback) {
-        int cb = callback(user_data, consumed, input_size);
-        if (cb) return (tamp_res)cb;
-    }
+    if (output_written_size) *output_written_size = written;
     return r;
 }
 
@@ -1400,6 +1390,17 @@ tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsig
     if (compat_segment_applies(s, input_size, output_size)) {
         r = compat_segment(compressor, output, output_size, output_written_size, input, input_size, write_token);
         if (r == TAMP_OK && input_consumed_size) *input_consumed_size = input_size;
+    } else if (input_size > kCompatPiece) {  // compressor.c:815-845 as it is written there: compress, then flush
+        size_t consumed = 0, written = 0, w2 = 0;
+        r = tamp_compressor_compress_cb(compressor, output, output_size, &written, input, input_size, &consumed, nullptr, nullptr);
+        if (r == TAMP_OK && consumed == input_size) {
+            r = tamp_compressor_flush(compressor, output + written, output_size - written, &w2, write_token);
+            written += w2;
+        } else if (r == TAMP_OK) {
+            r = TAMP_OUTPUT_FULL;
+        }
+        if (input_consumed_size) *input_consumed_size = consumed;
+        if (output_written_size) *output_written_size = written;
     } else {
         r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS_AND_FLUSH, write_token, output, output_size,
                                 output_written_size, input, input_size, input_consumed_size);
@@ -1445,40 +1446,68 @@ tamp_res tamp_compressor_reset_dictionary(TampCompressor* compressor, unsigned c
 tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, void* read_handle,
                               tamp_write_t write_cb, void* write_handle, size_t* input_consumed_size,
                               size_t* output_written_size, tamp_callback_t callback, void* user_data) {
-    // compressor.c:891-955: pull until EOF, compress, flush(write_token=false).  Here the pull fills one host
-    // buffer and the whole input is one segment on the device.
+    // compressor.c:891-955: pull, compress, push, until EOF; then flush(write_token=false).  The reference pumps a
+    // 32-byte work buffer; here the pull fills a host buffer of at most kStreamBuffer bytes (TAMP_AMD_STREAM_BUFFER_MB,
+    // default 64 MiB).  An input that ends inside the first fill is ONE segment for the batch kernel (the fast path:
+    // same bytes, tamp_compressor_compress_and_flush).  A longer one is fed buffer by buffer to
+    // tamp_compressor_compress on the same object -- exact at any cut, memory bounded -- and flushed at EOF.
     if (input_consumed_size) *input_consumed_size = 0;
     if (output_written_size) *output_written_size = 0;
     TampAmdEncoderState* s = enc_state(compressor);
     if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;
-    std::vector<unsigned char> in;
+    const size_t kStreamBuffer = env_or("TAMP_AMD_STREAM_BUFFER_MB", 64) << 20;
     constexpr size_t kChunk = 1 << 16;
+    std::vector<unsigned char> in, out;
+    size_t total_in = 0, total_out = 0;
+    auto push = [&](size_t n) -> tamp_res {
+        for (size_t at = 0; at < n;) {
+            const size_t k = std::min(n - at, kChunk);
+            int w = write_cb(write_handle, out.data() + at, k);
+            if (w < 0 || (size_t)w != k) return TAMP_WRITE_ERROR;
+            at += k, total_out += k;
+            if (output_written_size) *output_written_size = total_out;
+        }
+        return TAMP_OK;
+    };
+    bool eof = false, first = true;
     for (;;) {
-        const size_t at = in.size();
-        in.resize(at + kChunk);
-        int got = read_cb(read_handle, in.data() + at, kChunk);
-        if (got < 0) return TAMP_READ_ERROR;
-        in.resize(at + (size_t)got);
-        if (got == 0) break;
-        if (input_consumed_size) *input_consumed_size = in.size();
-        if (callback) {
-            int cb = callback(user_data, in.size(), 0);
+        in.clear();
+        while (!eof && in.size() < kStreamBuffer) {
+            const size_t at = in.size();
+            in.resize(at + kChunk);
+            int got = read_cb(read_handle, in.data() + at, kChunk);
+            if (got < 0) return TAMP_READ_ERROR;
+            in.resize(at + (size_t)got);
+            if (got == 0) eof = true;
+        }
+        total_in += in.size();
+        if (input_consumed_size) *input_consumed_size = total_in;
+        if (callback && !in.empty()) {  // once per read chunk, total unknown (common.h:198-200)
+            int cb = callback(user_data, total_in, 0);
             if (cb) return (tamp_res)cb;
         }
+        out.resize(tamp_amd_compress_bound(in.size(), s->literal, 1) + 24);
+        size_t written = 0, consumed = 0;
+        if (eof) {  // last (or only) buffer: compress + flush
+            tamp_res r = first ? tamp_compressor_compress_and_flush_cb(compressor, out.data(), out.size(), &written, in.data(),
+                                                                       in.size(), &consumed, false, nullptr, nullptr)
+                               : tamp_compressor_compress(compressor, out.data(), out.size(), &written, in.data(), in.size(), &consumed);
+            if (r != TAMP_OK) return r;
+            if (consumed != in.size()) return TAMP_ERROR;
+            if ((r = push(written)) != TAMP_OK) return r;
+            if (!first) {
+                r = tamp_compressor_flush(compressor, out.data(), out.size(), &written, false);
+                if (r != TAMP_OK) return r;
+                if ((r = push(written)) != TAMP_OK) return r;
+            }
+            return TAMP_OK;
+        }
+        tamp_res r = tamp_compressor_compress(compressor, out.data(), out.size(), &written, in.data(), in.size(), &consumed);
+        if (r != TAMP_OK) return r;
+        if (consumed != in.size()) return TAMP_ERROR;
+        if ((r = push(written)) != TAMP_OK) return r;
+        first = false;
     }
-    std::vector<unsigned char> out(tamp_amd_compress_bound(in.size(), s->literal, 1) + 24);
-    size_t written = 0, consumed = 0;
-    tamp_res r = tamp_compressor_compress_and_flush_cb(compressor, out.data(), out.size(), &written, in.data(), in.size(),
-                                                       &consumed, false, nullptr, nullptr);
-    if (r != TAMP_OK) return r;
-    for (size_t at = 0; at < written;) {
-        const size_t n = std::min(written - at, kChunk);
-        int w = write_cb(write_handle, out.data() + at, n);
-        if (w < 0 || (size_t)w != n) return TAMP_WRITE_ERROR;
-        at += n;
-        if (output_written_size) *output_written_size = at;
-    }
-    return TAMP_OK;
 }
 
 tamp_res tamp_decompress_stream(TampDecompressor* decompressor, tamp_read_t read_cb, void* read_handle,

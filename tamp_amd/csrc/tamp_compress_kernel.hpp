@@ -57,6 +57,7 @@ struct CompressArgs {
     uint16_t lead;      // those bytes, first one in the high byte
     uint8_t seg_flags;  // kSegResume | kSegSave | kSegFlushToken
     uint8_t* state;     // per stream: (1 << wbits) window bytes in ring order, then u16 window_pos, then u8 token-written flag
+    uint32_t* work_counter;    // TAMP_STREAM_LOOP builds: next stream index to hand out (zeroed before the launch)
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
 };
@@ -509,7 +510,7 @@ struct Walk {
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
 enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
 // ctl words
-enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13 };
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14 };
 
 #ifdef TAMP_PROF
 #define TAMP_PROF_MARK(i)                                     \
@@ -577,8 +578,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 
     const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
     uint32_t tid = tid_k;
-    const int lane = tid & (kWave - 1);
-    const uint32_t wave = tid >> 6;
+    int lane = tid & (kWave - 1);
+    uint32_t wave = tid >> 6;
     const uint32_t minp = (uint32_t)min_pattern_size((int)a_wbits, a.lbits);
     const bool ext = a.extended != 0;
     const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
@@ -589,7 +590,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     // One stream per workgroup (the launcher splits batches above 2^20 streams into several launches): with no
     // stream loop around it the compiler need not keep the batch tables' pointers alive past this point.
 #ifdef TAMP_STREAM_LOOP
-    for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
+    // Persistent workgroups: as many as fit the device at once, each fetching the next stream index from a counter until
+    // the batch is exhausted (dynamic: streams differ in cost, a static stride left the slowest workgroup 20 % behind).
+    for (;;) {
+        if (tid_k == 0) ctl[cNext] = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        const uint32_t s = Walk::uni(ctl[cNext]);
+        if (s >= a.n_streams) break;
 #else
     const uint32_t s = blockIdx.x + a.first_stream;
     {
@@ -643,6 +650,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             // (opaque re-definition: thread-indexed LDS addresses are recomputed per epoch instead of being hoisted out of
             // the stream loop, where they would sit in -- and spill from -- registers across every phase)
             asm volatile("" : "+v"(tid));
+            lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
             const uint32_t left = n - e_p0;
             const uint32_t nvalid = left < cur_blk ? left : cur_blk;
             const uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
@@ -673,6 +681,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 
                 // ---------------- index: counting sort of buffer positions by bigram ----------------
                 asm volatile("" : "+v"(tid));
+                lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
                 const uint32_t NE = nvalid ? W + nvalid : 0;  // positions 0..NE-1 (every query's own bigram included)
                 for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
                     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
@@ -821,6 +830,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 
                 // ---------------- match: find_best_match for every position of the block ----------------
                 asm volatile("" : "+v"(tid));
+                lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
                 const uint32_t nq = nvalid - e_pending;
 #ifdef TAMP_PROF
                 unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, niter = 0;
@@ -1414,6 +1424,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 
             // ---------------- emit: token list -> bits (all threads) ----------------
             asm volatile("" : "+v"(tid));
+            lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
             uint32_t act = ctl[cAct];
             const uint32_t ntok = ctl[cNtok];
             const uint32_t K = (ntok + nt - 1) / nt;

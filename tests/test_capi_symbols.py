@@ -151,33 +151,3 @@ def test_window_copy_host_helper():
         for i, b in enumerate(src):
             want[(pos + i) % W] = b
         assert bytes(buf) == bytes(want) and p.value == (pos + n) % W, (off, pos, n)
-
-
-def test_input_hint_sampler_needs_no_device():
-    """tamp_amd_input_hint (the sampling behind TAMP_AMD_HINT_AUTO): run-aware build for streams of 1 KiB and more,
-    lean build for short messages and, in the extended format, for data that is mostly runs."""
-    import numpy as np
-
-    from tamp_amd import _lib
-    from tamp_amd import workloads as wl
-
-    if not os.path.exists(_lib.LIB_PATH):
-        pytest.skip("libtamp_amd.so not built")
-    lib = _lib.load()
-
-    def hint(rows, extended=1):
-        rows = np.ascontiguousarray(rows, dtype=np.uint8)
-        n, L = rows.shape
-        off = (np.arange(n, dtype=np.uint64) * L)
-        ln = np.full(n, L, dtype=np.uint32)
-        return lib.tamp_amd_input_hint(rows.ctypes.data, off.ctypes.data, ln.ctypes.data, n, extended)
-
-    PLAIN, RUNS = 1, 2
-    assert hint(wl.synth_text(200, 4096)) == RUNS                  # streams of 1 KiB and more
-    code = ("def frobnicate(x, y=None):\n        return x + 1 if y is None else compute(x, y)\n\n" + "# " + "-" * 12 + " helpers\n            if x and not y:\n                raise ValueError(x)\n") * 2200
-    rows = np.frombuffer(code.encode()[: 64 * 4096], dtype=np.uint8).reshape(64, 4096)
-    assert hint(rows) == RUNS
-    assert hint(np.zeros((64, 4096), np.uint8)) == PLAIN          # all one run: the RLE path owns it
-    assert hint(np.zeros((64, 4096), np.uint8), extended=0) == RUNS  # ... but not in the v1 format
-    assert hint(wl.telemetry(4096, 256)) == PLAIN                  # short messages, mostly padding
-    assert lib.tamp_amd_input_hint(None, None, None, 0, 1) == PLAIN

@@ -349,3 +349,67 @@ def test_full_size_config5_one_gpu_share(ta, oracle):
     assert bool((back.out[: n * C].view(n, C)[:, :L][good] == data.view(n, L)[good]).all().item())
     print(f"\nconfigs[4] share: {n} x {L} B compress {r.kernel_ms:.2f} ms = {n * L / r.kernel_ms / 1e6:.1f} GB/s in, "
           f"decode {back.kernel_ms:.2f} ms = {n * L / back.kernel_ms / 1e6:.1f} GB/s out")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# boundary: tamp_compress_stream with bounded memory, progress callbacks
+# --------------------------------------------------------------------------------------------------------------
+def test_compress_stream_bounded_buffer_and_progress_callback(ta, oracle, monkeypatch):
+    """tamp_compress_stream (compressor.h:338, compressor.c:891-955) on an input longer than its host buffer: fed buffer
+    by buffer to ONE compressor object and flushed once -- the bytes of the one-shot call -- with the progress callback
+    (common.h:184-210) fired once per buffer as (bytes consumed so far, 0); tamp_compressor_compress_cb reports
+    (consumed, total) and a non-zero return aborts with that code."""
+    import ctypes as C
+
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    class MemReader(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    class MemWriter(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("capacity", C.c_size_t), ("pos", C.c_size_t)]
+
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
+    sz = C.POINTER(C.c_size_t)
+    lib.tamp_compressor_init.restype = C.c_int8
+    lib.tamp_compressor_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tamp_compress_stream.restype = C.c_int8
+    lib.tamp_compress_stream.argtypes = [C.c_void_p] * 5 + [sz, sz, CB, C.c_void_p]
+    lib.tamp_compressor_compress_cb.restype = C.c_int8
+    lib.tamp_compressor_compress_cb.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_void_p, C.c_size_t, sz, CB, C.c_void_p]
+    mem_read = C.cast(lib.tamp_stream_mem_read, C.c_void_p)
+    mem_write = C.cast(lib.tamp_stream_mem_write, C.c_void_p)
+    monkeypatch.setenv("TAMP_AMD_STREAM_BUFFER_MB", "1")
+    text = wl.synth_text(1, (2 << 20) + 70_001, first_index=77)[0].tobytes()  # three buffers: 1 MiB, 1 MiB, the rest
+    for ext in (1, 0):
+        st, want = oracle.compress(text, extended=bool(ext))
+        conf = TampConf(window=10, literal=8, extended=ext)
+        window, comp = (C.c_ubyte * 1024)(), (C.c_ubyte * 48)()
+        assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+        src = (C.c_ubyte * len(text)).from_buffer_copy(text)
+        dst = (C.c_ubyte * (len(text) + 4096))()
+        rd, wr = MemReader(C.addressof(src), len(text), 0), MemWriter(C.addressof(dst), len(text) + 4096, 0)
+        seen = []
+        cb = CB(lambda user, done, total: (seen.append((done, total)), 0)[1])
+        cin, cout = C.c_size_t(0), C.c_size_t(0)
+        assert lib.tamp_compress_stream(comp, mem_read, C.byref(rd), mem_write, C.byref(wr), C.byref(cin), C.byref(cout), cb, None) == 0
+        assert (cin.value, cout.value) == (len(text), len(want)) and bytes(dst[: wr.pos]) == want, ext
+        assert seen == [(1 << 20, 0), (2 << 20, 0), (len(text), 0)]
+    # callback of the object-level call: (consumed, total); a custom code in [100, 127] aborts and is passed through
+    conf = TampConf(window=10, literal=8, extended=1)
+    assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+    seen = []
+    cb = CB(lambda user, done, total: (seen.append((done, total)), 101)[1])
+    piece = text[:5000]
+    out, w, k = (C.c_ubyte * 8192)(), C.c_size_t(0), C.c_size_t(0)
+    buf = (C.c_ubyte * len(piece)).from_buffer_copy(piece)
+    assert lib.tamp_compressor_compress_cb(comp, out, 8192, C.byref(w), buf, len(piece), C.byref(k), cb, None) == 101
+    assert seen == [(5000, 5000)] and k.value == 5000
