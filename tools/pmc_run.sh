@@ -1,9 +1,12 @@
 #!/bin/bash
-# rocprofv3 evidence for the compress kernel.  Separate passes: kernel-trace/stats alone; each --pmc group alone
-# (FETCH_SIZE and WRITE_SIZE do not fit into one pass).
+# rocprofv3 evidence, round 2.  Separate passes: kernel-trace/stats alone; each --pmc group alone (FETCH_SIZE and WRITE_SIZE
+# do not fit into one pass).  Summaries land in gpurun_out/pmc_$TAG; copy what is to be tracked into profiles/.
+#   usage (GPU box, repo root): TAG=r2a bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_r1j; rm -rf $OUT; mkdir -p $OUT
+TAG=${TAG:-r2a}
+OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+# ---- compress kernel (configs[1], the bench command) ----
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
@@ -11,16 +14,26 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o sq -- $CMD > $OUT/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT -o sq2 -- $CMD > $OUT/sq2.log 2>&1
+# ---- decoders: BASELINE configs[3] at full size (1,048,576 streams, windows 2^8..2^12) ----
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec4_stats -- python tools/config4.py > $OUT/dec4_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o dec4_fetch -- python tools/config4.py > $OUT/dec4_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o dec4_write -- python tools/config4.py > $OUT/dec4_write.log 2>&1
+# ---- decoders on the bench batch (65,536 x 4 KiB, w=10), all three ----
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec2_stats -- python tools/dec_bench.py > $OUT/dec2_stats.log 2>&1
+# ---- real text, both formats ----
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o realtext_stats -- python tools/realtext.py > $OUT/realtext_stats.log 2>&1
 ls $OUT
 cat $OUT/bench.json
-python - <<'PY'
+python - <<PY
 import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/pmc_r1j/*counter_collection.csv')):
+for f in sorted(glob.glob('$OUT/*counter_collection.csv')):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'tamp_compress' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    print(f.split('/')[-1], {k: sum(v)/len(v) for k, v in acc.items()}, 'launches', {k: len(v) for k,v in acc.items()})
-for r in csv.DictReader(open('gpurun_out/pmc_r1j/stats_kernel_stats.csv')):
-    if 'tamp' in r['Name']: print(r)
+        if 'tamp_' in r['Kernel_Name'] and 'header_scan' not in r['Kernel_Name']:
+            acc[(r['Kernel_Name'][:60], r['Counter_Name'])].append(float(r['Counter_Value']))
+    print(f.split('/')[-1], {k: (round(sum(v)/len(v)), len(v)) for k, v in acc.items()})
+for f in sorted(glob.glob('$OUT/*_kernel_stats.csv')):
+    for r in csv.DictReader(open(f)):
+        if 'tamp' in r['Name']: print(f.split('/')[-1], r['Name'][:70], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
 PY
+grep -h "GB/s" $OUT/dec4_stats.log $OUT/dec2_stats.log $OUT/realtext_stats.log
