@@ -46,8 +46,7 @@ class Shard:
             self.data = torch.from_numpy(np.ascontiguousarray(flat)).to(device)
             self.off = torch.from_numpy(np.asarray(in_off, dtype=np.int64)).to(device)
             self.len = torch.from_numpy(np.asarray(in_len, dtype=np.int32)).to(device)
-            cap1 = tamp_amd.compress_bound(self.max_len, 8)
-            self.cap = torch.full((self.n,), cap1, dtype=torch.int32, device=device)
+            self.cap = tamp_amd.compress_bound(self.max_len, 8)  # uniform slabs: the launch needs no device round trip
         self.kw = dict(conf_kw, max_in_len=self.max_len, out_cap=self.cap)
         self.torch = torch
         self.events = []

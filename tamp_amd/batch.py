@@ -108,10 +108,13 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
 
         n = int(in_len.numel())
         dev = data.device
-        if out_cap is None:
-            if not max_in_len:
-                max_in_len = int(in_len.max().item()) if n else 0
-            cap1 = compress_bound(max_in_len, literal, dictionary_reset)
+        if out_cap is None or isinstance(out_cap, int):
+            if isinstance(out_cap, int):
+                cap1 = out_cap  # one capacity for every stream: no device round trip to lay the slabs out
+            else:
+                if not max_in_len:
+                    max_in_len = int(in_len.max().item()) if n else 0
+                cap1 = compress_bound(max_in_len, literal, dictionary_reset)
             out_cap_t = torch.full((n,), cap1, dtype=torch.int32, device=dev)
             out_off_t = torch.arange(n, dtype=torch.int64, device=dev) * cap1
             total = n * cap1

@@ -413,3 +413,25 @@ def test_compress_stream_bounded_buffer_and_progress_callback(ta, oracle, monkey
     buf = (C.c_ubyte * len(piece)).from_buffer_copy(piece)
     assert lib.tamp_compressor_compress_cb(comp, out, 8192, C.byref(w), buf, len(piece), C.byref(k), cb, None) == 101
     assert seen == [(5000, 5000)] and k.value == 5000
+
+
+def test_bench_under_torch_distributed_run_two_ranks_one_device(ta):
+    """The launch line the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), two ranks sharing
+    the one device of this box: gloo for the barrier / MAX only, totals summed over ranks, one JSON line from rank 0."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TAMP_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--streams", "4096"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["streams_total"] == 8192 and line["config"]["all_streams_ok"]
+    assert "gloo" in line["config"]["parallelism"] and "cpu_baseline" not in line
