@@ -435,3 +435,32 @@ def test_bench_under_torch_distributed_run_two_ranks_one_device(ta):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["streams_total"] == 8192 and line["config"]["all_streams_ok"]
     assert "gloo" in line["config"]["parallelism"] and "cpu_baseline" not in line
+
+
+def test_command_line_round_trip(ta, oracle, tmp_path):
+    """python -m tamp_amd compress / decompress (tamp/cli/main.py:115-232): files and pipes, an undersized dictionary file
+    (raw effective bytes copied to the end of the seeded default), empty input -> "No data provided."."""
+    from tamp_amd import workloads as wl
+
+    text = wl.synth_text(1, 20000, first_index=5)[0].tobytes()
+    src, comp, back, dct = tmp_path / "in.txt", tmp_path / "out.tamp", tmp_path / "back.txt", tmp_path / "d.bin"
+    src.write_bytes(text)
+    dct.write_bytes(text[:300])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda *a, **k: subprocess.run([sys.executable, "-m", "tamp_amd", *a], capture_output=True, timeout=300, env=env, cwd=ROOT, **k)  # noqa: E731
+    r = run("compress", "-i", str(src), "-o", str(comp), "-w", "9", "--lazy-matching")
+    assert r.returncode == 0, r.stderr
+    assert comp.read_bytes() == oracle.compress(text, window=9, lazy_matching=True)[1]
+    r = run("decompress", str(comp), str(back))
+    assert r.returncode == 0 and back.read_bytes() == text
+    r = run("compress", "-d", str(dct), "-w", "10", "-l", "7", input=text)  # stdin -> stdout, raw dictionary
+    assert r.returncode == 0, r.stderr
+    full = ta.initialize_dictionary(1024, literal=7)
+    full[-300:] = text[:300]
+    assert r.stdout == oracle.compress(text, window=10, literal=7, dictionary=bytes(full))[1]
+    r2 = run("decompress", "-d", str(dct), "-l", "7", input=r.stdout)
+    assert r2.returncode == 0 and r2.stdout == text
+    empty = tmp_path / "empty"
+    empty.write_bytes(b"")
+    r = run("compress", "-i", str(empty))
+    assert r.returncode == 1 and b"No data provided." in r.stderr

@@ -162,3 +162,36 @@ def test_bench_host_helpers():
     assert isinstance(bench.cpu_model(), str)
     traffic, src = bench.pmc_traffic_bytes()
     assert traffic is None or traffic > 0
+
+
+def test_cli_dictionary_rule_and_arguments(tmp_path):
+    """tamp/cli/main.py:90-105: a dictionary file of the window's size is taken as it is, a shorter one is copied to the END of
+    the seeded default, a longer one is an error; option names and ranges of the two commands."""
+    import os
+
+    from tamp_amd import _lib, cli
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libtamp_amd.so not built")
+    full = bytes(range(256)) * 4
+    p = tmp_path / "full.bin"
+    p.write_bytes(full)
+    assert cli.load_dictionary(p, 10, 8, True) == bytearray(full)
+    q = tmp_path / "raw.bin"
+    q.write_bytes(b"hello world")
+    d = cli.load_dictionary(q, 10, 7, True)
+    seeded = tamp_amd.initialize_dictionary(1024, literal=7)
+    assert len(d) == 1024 and d[-11:] == b"hello world" and d[:-11] == seeded[:-11]
+    assert cli.load_dictionary(q, 10, 7, False)[:-11] == tamp_amd.initialize_dictionary(1024, literal=8)[:-11]  # v1: literal-8 table
+    big = tmp_path / "big.bin"
+    big.write_bytes(bytes(2000))
+    with pytest.raises(ValueError):
+        cli.load_dictionary(big, 10, 8, True)
+    ap = cli.build_parser()
+    a = ap.parse_args(["compress", "-i", "x", "-o", "y", "-w", "12", "-l", "7", "--lazy-matching", "--no-extended"])
+    assert (a.input, a.output, a.window, a.literal, a.lazy_matching, a.extended) == ("x", "y", 12, 7, True, False)
+    a = ap.parse_args(["decompress", "in.tamp", "out.bin", "-d", "dict.bin"])
+    assert (a.input_pos, a.output_pos, a.dictionary, a.window, a.extended) == ("in.tamp", "out.bin", "dict.bin", 10, True)
+    for bad in (["compress", "-w", "7"], ["compress", "-l", "9"], ["decompress", "--lazy-matching"]):
+        with pytest.raises(SystemExit):
+            ap.parse_args(bad)
