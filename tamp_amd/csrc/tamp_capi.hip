@@ -24,6 +24,7 @@
 #include "tamp_compat.h"
 #include "tamp_compress_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
+#include "tamp_decompress_split_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
 #include "tamp_decompress_resume_kernel.hpp"
 #include "tamp_compress_resume_kernel.hpp"
@@ -48,7 +49,9 @@ struct DeviceCtx {
     struct Slab {
         uint8_t* p = nullptr;
         size_t bytes = 0;
-        uint32_t* scan = nullptr;  // header pre-pass results (largest window / longest stream / window bytes)
+        uint32_t* scan = nullptr;  // header pre-pass results (largest window / longest stream / window bytes / largest out_cap)
+        uint8_t* split = nullptr;  // split decoder: token records, per-stream meta words, lag lists, fallback flags
+        size_t split_bytes = 0;
     };
     std::map<hipStream_t, Slab> slabs;
     // host-memory batch calls (TAMP_AMD_MEM_HOST): kept staging buffers and the library's own streams, so that a
@@ -293,11 +296,13 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
 // Largest window (bits) any stream header of the batch asks for, among those the caller's limit admits.  LDS rows of the
 // decoders are sized from it instead of from the limit: a caller that passes the API default (15) for 1 KiB-window
 // streams would otherwise run at a fraction of the occupancy.
-__global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
-                                        uint32_t limit, uint32_t* result) {
+__global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                                        const uint32_t* out_cap, uint32_t n, uint32_t limit, uint32_t* result) {
     uint32_t m = 0, longest = 0, wsum = 0;  // wsum: window bytes / 256, summed over the streams within the limit
+    uint32_t maxcap = 0;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const uint32_t len = in_len[s];
+        maxcap = out_cap[s] > maxcap ? out_cap[s] : maxcap;
         if (len == 0) continue;
         longest = len > longest ? len : longest;
         const uint32_t w = 8u + (in[in_off[s]] >> 5);  // header byte, decompressor.c:276-297
@@ -308,12 +313,14 @@ __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_of
     }
     m = wave_max_u32(m);
     longest = wave_max_u32(longest);
+    maxcap = wave_max_u32(maxcap);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, off);
     if ((threadIdx.x & (kWave - 1)) == 0) {
         if (m) atomicMax(result, m);
         atomicMax(result + 1, longest);
         atomicAdd(result + 2, wsum);
+        atomicMax(result + 3, maxcap);
     }
 }
 
@@ -329,12 +336,16 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.dict = d_dict, a.dict_len = (uint32_t)(dict_len > 0xFFFFFFFFu ? 0xFFFFFFFFu : dict_len);
     a.seed_dicts = ctx->seed_dicts;
     a.scratch = nullptr;
+    a.only_flagged = nullptr;
     a.n_streams = (uint32_t)n_streams;
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
     uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)
     uint64_t window_bytes = 0;          // sum of the streams' window sizes (0 = unknown)
+    uint32_t max_out_cap = 0;           // largest out_cap of the batch (0 = unknown)
     max_wbits &= 0x7F;
-    if (!exact && max_wbits > 8 && max_wbits <= 15 && n_streams >= 256) {
+    const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" | "global" | "split" (tuning / tests)
+    const bool force_split = force && force[0] == 's';
+    if (!exact && max_wbits >= 8 && max_wbits <= 15 && ((max_wbits > 8 && n_streams >= 256) || force_split)) {
         uint32_t* hdr_scan = nullptr;
         {
             std::lock_guard<std::mutex> lock(g_mu);
@@ -342,24 +353,86 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
             if (!slab.scan) HIP_OK(hipMalloc(&slab.scan, 32));
             hdr_scan = slab.scan;
         }
-        uint32_t scan[3] = {0, 0, 0};
+        uint32_t scan[4] = {0, 0, 0, 0};
         uint32_t& found = scan[0];
-        HIP_OK(hipMemsetAsync(hdr_scan, 0, 12, st));
+        HIP_OK(hipMemsetAsync(hdr_scan, 0, 16, st));
         const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
-        hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, (uint32_t)n_streams,
-                           (uint32_t)max_wbits, hdr_scan);
-        HIP_OK(hipMemcpyAsync(scan, hdr_scan, 12, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, d_out_cap,
+                           (uint32_t)n_streams, (uint32_t)max_wbits, hdr_scan);
+        HIP_OK(hipMemcpyAsync(scan, hdr_scan, 16, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         // streams above the limit fail with TAMP_INVALID_CONF under either value; nothing valid exceeds `found`
         if (found >= 8 && found < max_wbits) max_wbits = (uint8_t)found;
         if (found == 0) max_wbits = 8;
         longest_in = scan[1];
         window_bytes = (uint64_t)scan[2] << 8;
+        max_out_cap = scan[3];
     }
-    const char* force = getenv("TAMP_AMD_DECODER");  // "wave" | "lane" | "global" (tuning / tests)
     a.max_wbits = max_wbits;
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
+    // Split decoder (tamp_decompress_split_kernel.hpp): parse one lane per stream without any window, resolve one
+    // workgroup per stream by pointer jumping; what it flags is decoded by the wave decoder afterwards.  Needs the
+    // pre-pass (longest stream and largest out_cap size its scratch and LDS).
+    // Taken for batches of streams of 512 compressed bytes and more (short messages: the lean lane decoder with its LDS rows
+    // is three to six times faster, tools/dec_bench.py) whose output slabs fit RESOLVE's LDS.
+    const bool split_fits = valid_bits && max_out_cap && max_out_cap <= kSplitMaxOut && longest_in != 0xFFFFFFFFu;
+    const bool want_split = force ? force_split : (longest_in >= 512 && n_streams >= 256);
+    if (want_split && split_fits) {
+        SplitArgs sa;
+        sa.maxcap = max_out_cap;
+        sa.tokcap = std::max<uint32_t>(16, (uint32_t)std::min<uint64_t>(max_out_cap, (uint64_t)longest_in * 8 / 6 + 8));
+        const size_t slice = std::min<size_t>(n_streams, (size_t)1 << 17);
+        const size_t b_recs = slice * sa.tokcap * 4, b_meta = slice * 4, b_lag = slice * kSplitMaxLag * 8;
+        const size_t need = b_recs + b_meta + b_lag + n_streams + 64;
+        uint8_t* base = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            DeviceCtx::Slab& slab = ctx->slabs[st];
+            if (slab.split_bytes < need) {
+                if (slab.split) {
+                    HIP_OK(hipStreamSynchronize(st));
+                    HIP_OK(hipFree(slab.split));
+                    slab.split = nullptr, slab.split_bytes = 0;
+                }
+                HIP_OK(hipMalloc(&slab.split, need));
+                slab.split_bytes = need;
+            }
+            base = slab.split;
+        }
+        sa.recs = reinterpret_cast<uint32_t*>(base);
+        sa.meta = reinterpret_cast<uint32_t*>(base + b_recs);
+        sa.lag = reinterpret_cast<uint32_t*>(base + b_recs + b_meta);
+        sa.flagged = base + b_recs + b_meta + b_lag;
+        sa.d = a;
+        const uint32_t lds = split_resolve_lds(max_out_cap);
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decode_resolve_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        timing_begin(st);
+        for (size_t first = 0; first < n_streams; first += slice) {
+            sa.first = (uint32_t)first;
+            sa.count = (uint32_t)std::min(slice, n_streams - first);
+            // streams per wave: enough waves for ~4 per SIMD (tools/dec_split_pmc.sh: the parse runs at one wave's latency)
+            const size_t want_waves = (size_t)ctx->cu_count * 16;
+            sa.spw = sa.count / 16 < want_waves ? 16 : (sa.count / 32 < want_waves ? 32 : 64);
+            if (const char* e = getenv("TAMP_AMD_SPLIT_SPW")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) sa.spw = (uint32_t)v; }
+            const uint32_t pwaves = (sa.count + sa.spw - 1) / sa.spw;
+            hipLaunchKernelGGL(tamp_decode_parse_kernel, dim3((pwaves + 3) / 4), dim3(256), split_parse_lds(256), st, sa);
+            hipLaunchKernelGGL(tamp_decode_resolve_kernel, dim3(sa.count), dim3(256), lds, st, sa);
+        }
+        // leftovers: the wave decoder over the flagged streams only
+        a.only_flagged = sa.flagged;
+        const uint32_t waves = max_wbits <= 12 ? 4 : 1;
+        const uint32_t wlds = decode_wave_lds(max_wbits, waves);
+        size_t groups = (n_streams + waves - 1) / waves;
+        groups = std::min(groups, (size_t)ctx->cu_count * 64);
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decompress_wave_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        hipLaunchKernelGGL(tamp_decompress_wave_kernel, dim3((uint32_t)groups), dim3(waves * kWave), wlds, st, a);
+        timing_end(st);
+        HIP_OK(hipGetLastError());
+        return TAMP_OK;
+    }
     // Decoder choice: one wavefront per stream (scalar token loop, window in LDS, 64-lane copies) unless the batch is
     // a very large number of streams, where one lane per stream fills the chip and avoids per-stream set-up.
     // Three decoders.  Wave per stream: time follows the total bytes, needs few streams.  Lane per
@@ -481,6 +554,7 @@ int launch_decompress_resume(DeviceCtx* ctx, uint8_t* d_states, size_t stride, u
     a.dict = nullptr, a.dict_len = 0;  // a custom dictionary is the initial content of the object's window
     a.seed_dicts = ctx->seed_dicts;
     a.scratch = nullptr;
+    a.only_flagged = nullptr;
     a.n_streams = (uint32_t)n_streams;
     a.lds_row = 0;
     a.max_wbits = bits_max;

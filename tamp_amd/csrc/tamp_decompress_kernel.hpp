@@ -38,6 +38,8 @@ struct DecompressArgs {
     uint32_t dict_len;
     const uint8_t* seed_dicts;  // 3 tables of 1<<15 bytes: literal<=5, literal==6, literal>=7 (common.c:18-25)
     uint8_t* scratch;           // global variant: one window slot of (1 << max_wbits) bytes per resident lane
+    const uint8_t* only_flagged;  // null, or one byte per stream: decode only the streams whose byte is set (what the
+                                  // split decoder, tamp_decompress_split_kernel.hpp, left over)
     uint32_t n_streams;
     uint32_t lds_row;           // LDS variant: bytes per lane row = (1 << max_wbits) + 4
     uint8_t max_wbits;
@@ -134,6 +136,7 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
     }
 
     for (uint32_t s = gtid; s < a.n_streams; s += nthreads) {
+        if (a.only_flagged && !a.only_flagged[s]) continue;
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
         uint8_t* const out = a.out + a.out_off[s];

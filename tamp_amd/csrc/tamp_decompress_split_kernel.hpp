@@ -1,0 +1,600 @@
+// tamp_decompress_split_kernel.hpp -- batch `.tamp` decoder for gfx950 in two kernels: parse, then resolve.
+//
+// Replaces, per stream, tamp_decompressor_init(conf=NULL) + tamp_decompressor_decompress
+// (tamp/_c_src/tamp/decompressor.c:331-347,371-578), like tamp_decompress_kernel.hpp -- same statuses, sizes and consumed
+// counts -- but splits the work where the dependencies are:
+//
+//   * PARSE (tamp_decode_parse_kernel, one lane per stream, no window, no LDS): the bit-serial part.  It is the
+//     reference's token loop (bit buffer, refill rule, prefix code, RLE / extended-match payloads, FLUSH, the out-of-bounds
+//     rule, partial tokens when the output fills up: decompressor.c:357-365,431-575) with every data movement taken out:
+//     what it leaves behind per token is a 32-bit record (kind, bytes produced, window offset or literal), per stream the
+//     final status / size / consumed count, and a short list of the tokens that wrote fewer bytes to the window than they
+//     produced (RLE runs over 8 bytes, tokens clipped at the ring end: decompressor.c:140-173,229-272).  With no window
+//     to keep per lane the kernel is bound by instruction issue, not by LDS capacity or cache-resident windows as the
+//     lane-per-stream decoders are (13-16 % VALU busy, tools/dec_pmc2.sh).
+//   * RESOLVE (tamp_decode_resolve_kernel, one workgroup per stream): the data part, parallel over the stream's bytes.
+//     Every byte ever written to the window has a virtual position v (the dictionary sits at v = -W .. -1); ring index i
+//     holds, when V bytes have been written, the byte with v = V - 1 - ((V - 1 - i) mod W).  A copy token therefore names,
+//     for each byte it produces, an EARLIER output byte or a dictionary byte -- sources are read in the window as it was
+//     before the token (decompressor.c:564-572, tamp_window_copy common.c:58-86: memmove semantics), so the pointers run
+//     strictly backwards.  The records are expanded to one pointer per output byte, the pointers are resolved by pointer
+//     jumping (each round halves every chain), and the finished bytes leave as coalesced dwords.  No window exists at all,
+//     so any window size costs the same.
+//
+// Streams the two kernels do not cover are flagged by PARSE and decoded by the lane / wave decoders afterwards
+// (DecompressArgs::only_flagged): a dictionary reset inside the stream (double FLUSH, decompressor.c:501-514), more
+// tokens or lagging tokens than the scratch slots hold.  Scalar model: the oracle's decoder (oracle/tamp_oracle.c); parity
+// and status / consumed semantics are tested against it for every decoder (tests/test_gpu_parity.py, tools/fuzz_gpu.py).
+#pragma once
+#include "tamp_common.hpp"
+#include "tamp_decompress_kernel.hpp"
+
+namespace tamp_amd {
+
+constexpr uint32_t kSplitMaxLag = 48;      // lagging tokens listed per stream (more: the stream is left to the lane decoders)
+constexpr uint32_t kSplitMaxOut = 16384;   // bytes of output RESOLVE keeps in LDS (out_cap above: not a split-decoder batch)
+__host__ __device__ constexpr uint32_t split_resolve_lds(uint32_t maxcap) {
+    // bytes + 16, one u16 pointer per byte, lag list, control words
+    return ((maxcap + 15u) & ~15u) * 3u + 16u + kSplitMaxLag * 8u + 64u;
+}
+
+// record = kind | out_len << 2 | arg << 10;  arg = literal byte, or the window offset of a copy
+enum : uint32_t { kRecLit = 0, kRecCopy = 1, kRecFill = 2, kRecCopyExt = 3 };
+// meta = ntok | wbits-8 << 20 | dict_sel << 23 | nlag << 25 | fallback << 31
+constexpr uint32_t kMetaFallback = 1u << 31;
+
+struct SplitArgs {
+    DecompressArgs d;        // the batch (d.only_flagged is not used by these kernels)
+    uint32_t* recs;          // n_streams x tokcap records
+    uint32_t* meta;          // n_streams
+    uint32_t* lag;           // n_streams x kSplitMaxLag x 2: (Oend | Vend << 16), cumulative lag
+    uint8_t* flagged;        // n_streams: 1 = left to the lane / wave decoders
+    uint32_t tokcap;         // records per stream
+    uint32_t maxcap;         // largest out_cap of the batch (sizes RESOLVE's LDS)
+    uint32_t first;          // first stream of this slice
+    uint32_t count;          // streams in this slice
+    uint32_t spw;            // PARSE: streams per wavefront (16, 32 or 64).  The parse is a serial chain per stream and
+                             // bound by latency, not issue, until every SIMD holds several waves: small batches spread
+                             // their streams over more, partly filled waves
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// PARSE: the reference's token loop without the data (compare tamp_decompress_kernel.hpp, exact loop)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kParseRing = 64, kParseLane = 68;  // per lane: 64-byte input ring in LDS, odd dword stride
+__host__ __device__ constexpr uint32_t split_parse_lds(uint32_t threads) { return 128u + threads * kParseLane; }
+
+__global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DecompressArgs& a = sa.d;
+    uint8_t* const lut = smem;  // prefix-code LUT: index = the 7 bits after the leading 1 -> (extra bits << 4) | symbol
+    for (uint32_t v = threadIdx.x; v < 128; v += blockDim.x) {
+        const uint64_t codes_lo = 0x2b2624140b080300ull, codes_hi = 0x00ab27aa9594544bull, nbits = 0x979998877765532ull;
+        uint32_t entry = 0;
+        for (int sy = 1; sy < 15; sy++) {
+            const uint32_t l = (uint32_t)((nbits >> (4 * sy)) & 15) - 1u;  // code length without the flag: 2..8
+            const uint32_t code = (uint32_t)((sy < 8 ? codes_lo >> (8 * sy) : codes_hi >> (8 * (sy - 8))) & 0xFF);
+            if ((code & ((1u << (l - 1)) - 1)) == (v >> (7 - (l - 1)))) entry = ((l - 1) << 4) | (uint32_t)sy;
+        }
+        lut[v] = (uint8_t)entry;
+    }
+    __syncthreads();
+    const uint32_t k = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * sa.spw + (threadIdx.x & (kWave - 1));
+    const bool live = (threadIdx.x & (kWave - 1)) < sa.spw && k < sa.count;
+    const uint32_t s = sa.first + (live ? k : 0u);
+    const uint8_t* const in = a.in + a.in_off[s];
+    const uint32_t n = live ? a.in_len[s] : 0u;
+    const uint32_t cap = a.out_cap[s];
+    uint32_t* const rec = sa.recs + (size_t)(live ? k : 0u) * sa.tokcap;
+    uint32_t* const lag = sa.lag + (size_t)(live ? k : 0u) * kSplitMaxLag * 2;
+    uint8_t* const inr = smem + 128 + threadIdx.x * kParseLane;
+    uint32_t ip = 0, op = 0, ntok = 0, nlag = 0, cumlag = 0;
+    uint32_t V = 0;  // bytes written to the window so far (window_pos = V mod W on a fresh decoder)
+    uint32_t wbits = 8, dict_sel = 2;
+    bool fallback = false;
+    int res = kInputExhausted;
+
+    do {
+        if (n > kMaxDecodeIn) { res = kBadArgument; break; }
+        if (a.max_wbits < 8 || a.max_wbits > 15) { res = kInvalidConf; break; }  // decompressor.c:336
+        if (n == 0) break;
+        const uint32_t h0 = in[0];
+        const uint32_t hs = 1 + (h0 & 1);
+        if (n < hs) { ip = 1; break; }  // decompressor.c:405-410
+        if (hs == 2 && in[1]) { res = kInvalidConf; break; }
+        ip = hs;
+        wbits = ((h0 >> 5) & 7) + 8;
+        const uint32_t lbits = ((h0 >> 3) & 3) + 5;
+        const bool custom = (h0 >> 2) & 1, extended = (h0 >> 1) & 1, dreset = h0 & 1;
+        if (wbits > a.max_wbits) { res = kInvalidConf; break; }  // decompressor.c:311
+        const uint32_t W = 1u << wbits, mask = W - 1;
+        const uint32_t minp = (uint32_t)min_pattern_size((int)wbits, (int)lbits);
+        dict_sel = (!extended || lbits >= 7) ? 2u : (lbits == 6 ? 1u : 0u);  // decompressor.c:318-319
+        if (custom) {
+            if (!a.dict || a.dict_len < W) { res = kInvalidConf; break; }
+            dict_sel = 3;
+        }
+        if (cap > sa.maxcap) fallback = true;  // (cannot happen: maxcap is the batch maximum)
+
+        // one record; `written` = bytes of it that enter the window
+        auto put = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written) {
+            if (olen == 0) return;
+            if (ntok >= sa.tokcap) {
+                fallback = true;
+            } else {
+                rec[ntok] = kind | (olen << 2) | (arg << 10);
+            }
+            ntok++;
+            op += olen;
+            V += written;
+            if (written < olen) {  // a lag: later window offsets name bytes further back in the output
+                cumlag += olen - written;
+                if (nlag < kSplitMaxLag) {
+                    lag[2 * nlag] = (op & 0xFFFFu) | ((V & 0xFFFFu) << 16);
+                    lag[2 * nlag + 1] = cumlag;
+                } else {
+                    fallback = true;
+                }
+                nlag++;
+            }
+        };
+
+        uint32_t bb = 0, nb = 0, stage = 0, ns = 0;
+        bool last_flush = false;
+        auto refill = [&]() {  // decompressor.c:357-365; bytes reach `stage` a dword at a time
+            while (ip < n && nb <= 24) {
+                if (ns == 0) {
+                    const uint8_t* p = in + ip;
+                    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0 && ip + 4 <= n) {
+                        stage = *reinterpret_cast<const uint32_t*>(p);
+                        ns = 4;
+                    } else {
+                        stage = *p;
+                        ns = 1;
+                    }
+                }
+                nb += 8;
+                bb |= (stage & 0xFFu) << (32 - nb);
+                stage >>= 8;
+                ns--;
+                ip++;
+            }
+        };
+
+        // Two loops alternate.  FAST: straight-line decode from a 64-bit bit window (the token decode of the lane
+        // decoders' bulk path, tamp_decompress_kernel.hpp, without its data movement), input through a 64-byte ring per lane
+        // that 16-byte global loads refill at points common to the wave.  It declines -- at a token boundary, nothing
+        // consumed -- whatever it does not cover: the last ~32 input bytes, FLUSH, a token the output has no room for, an
+        // out-of-bounds offset, a dry ring.  EXACT: the reference's own loop, rebuilt from the bit position (including the
+        // refill cursor that decides the consumed count), takes two tokens and hands back, or finishes the stream.
+        const bool use_fast = n >= hs + 160;
+        for (;;) {
+        bool resume = false;
+        uint32_t budget = 0xFFFFFFFFu;
+        if (use_fast) {
+            uint32_t T = 8 * ip - nb;  // bits consumed from the start of the stream
+            const uint32_t sp = T >> 3;
+            bool fast = sp + 32 <= n;
+            const uint32_t sp0 = sp;  // stream byte x lives at inr[(x - sp0) & 63]
+            auto ring_u32 = [&](uint32_t x) { return *reinterpret_cast<const uint32_t*>(inr + ((x - sp0) & (kParseRing - 1))); };
+            B16 cb = {{0, 0, 0, 0}};
+            bool cb_valid = false;
+            uint32_t rp = sp, fill = sp, ld_off = sp, wnext = 0, fn = 0;
+            uint64_t fb = 0;
+            if (fast) {
+                st16(inr, ld16(in + sp));
+                st16(inr + 16, ld16(in + sp + 16));
+                fill = ld_off = sp + 32;
+                fb = (uint64_t)__builtin_bswap32(ring_u32(sp)) << (32 + (T & 7));
+                fn = 32 - (T & 7);
+                rp = sp + 4;
+                wnext = ring_u32(rp);
+                budget = 2;
+            }
+            const uint32_t T_in = T;
+            uint32_t T_mark = T;  // bit position at the reference's most recent refill
+            auto refill32 = [&]() -> bool {
+                if (rp + 4 > fill) return false;
+                fb |= (uint64_t)__builtin_bswap32(wnext) << (32 - fn);
+                fn += 32;
+                rp += 4;
+                wnext = ring_u32(rp);  // (may be a stale slot: it is not used before `fill` has passed it)
+                return true;
+            };
+            uint32_t step = 0;
+            while (__ballot(fast)) {
+                if ((step++ & 3) == 0 && fast) {  // ---- I/O point ----
+                    if (cb_valid && fill + 16 - (rp - 4) <= kParseRing) {
+                        st16(inr + ((fill - sp0) & (kParseRing - 1)), cb);
+                        if (fill == rp) wnext = cb.w[0];
+                        fill += 16;
+                        cb_valid = false;
+                    }
+                    if (!cb_valid && ld_off + 16 <= n) {
+                        cb = ld16(in + ld_off);
+                        ld_off += 16;
+                        cb_valid = true;
+                    }
+                }
+                if (!fast) continue;
+                const uint32_t T0 = T;
+                bool ok = fn >= 32 || refill32();
+                uint32_t used = 0, tok = 0, wl = 0, kind = kRecLit, arg = 0;
+                uint32_t mark = T0;  // the reference refills at the top of every token (decompressor.c:357-365,431-445)
+                const uint32_t wp = V & mask, room = cap - op;
+                if (ok) {
+                    if (fb >> 63) {  // literal, decompressor.c:466-482
+                        arg = (uint32_t)((fb << 1) >> (64 - lbits));
+                        used = 1 + lbits, tok = 1, wl = 1, kind = kRecLit;
+                        ok = room >= 1;
+                    } else {
+                        uint32_t sym = 0;
+                        used = 2;
+                        if ((fb >> 62) & 1) {
+                            const uint32_t e = lut[(uint32_t)(fb >> 55) & 0x7F];
+                            sym = e & 15, used = 2 + (e >> 4);
+                        }
+                        if (sym == kSymFlush) {
+                            ok = false;
+                        } else if (!extended || sym < kSymRle) {  // plain match, decompressor.c:529-572
+                            tok = sym + minp;
+                            arg = (uint32_t)((fb << used) >> (64 - wbits));
+                            used += wbits;
+                            wl = tok, kind = kRecCopy;
+                            ok = arg + tok <= W && tok <= room;
+                        } else {  // RLE / extended match, decompressor.c:114-273
+                            fb <<= used, fn -= used, T += used;
+                            ok = fn >= 32 || refill32();
+                            if (ok) {
+                                const uint32_t trailing = sym == kSymRle ? 4u : 3u;
+                                uint32_t h = 0, u = 1;
+                                if (fb >> 63) {
+                                    const uint32_t e = lut[(uint32_t)(fb >> 56) & 0x7F];
+                                    h = e & 15, u = 1 + (e >> 4);
+                                }
+                                const uint32_t value = (h << trailing) + (uint32_t)((fb << u) >> (64 - trailing));
+                                u += trailing;
+                                if (sym == kSymRle) {
+                                    tok = value + 2;
+                                    wl = min(min(tok, kRleWindowMax), W - wp);
+                                    kind = kRecFill, arg = 0;
+                                    ok = tok <= room;
+                                } else {
+                                    tok = value + minp + 12;
+                                    arg = (uint32_t)((fb << u) >> (64 - wbits));
+                                    // ... and once more in front of the offset if its buffer (25..32 bits after the
+                                    // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
+                                    const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
+                                    if (nb_top - (T - T0) - u < wbits) mark = T + u;
+                                    u += wbits;
+                                    wl = min(tok, W - wp);
+                                    kind = kRecCopyExt;
+                                    ok = arg + tok <= W && tok <= room;
+                                }
+                                used = u;
+                            }
+                        }
+                    }
+                }
+                if (!ok) {  // (bits of a half-read RLE / extended token are simply read again by the exact loop)
+                    T = T0;
+                    fast = false;
+                    continue;
+                }
+                fb <<= used, fn -= used, T += used;
+                T_mark = mark;
+                put(kind, tok, arg, wl);
+            }
+            if (T != T_in) {  // the reference's buffer at this token boundary: everything its last refill pulled in
+                last_flush = false;
+                const uint32_t ip_ref = min(n, ((T_mark + 24) >> 3) + 1);
+                bb = 0, nb = 0, stage = 0, ns = 0;
+                for (uint32_t b = T >> 3; b < ip_ref; b++) {
+                    uint32_t byte = in[b], width = 8;
+                    if (b == (T >> 3)) byte &= 0xFFu >> (T & 7), width = 8 - (T & 7);
+                    bb |= byte << (32 - nb - width);
+                    nb += width;
+                }
+                ip = ip_ref;
+            }
+        }
+
+        for (;;) {  // decompressor.c:431-575
+            if (use_fast && budget-- == 0) {  // back to the fast loop (it declines by itself near the end of the input)
+                resume = true;
+                break;
+            }
+            if (!(ip < n || nb)) break;
+            if (op == cap) { res = kOutputFull; break; }
+            refill();
+            if (nb == 0) break;
+
+            if (bb >> 31) {  // literal, decompressor.c:466-482
+                last_flush = false;
+                if (nb < 1 + lbits) break;
+                const uint32_t c = (bb << 1) >> (32 - lbits);
+                bb <<= 1 + lbits;
+                nb -= 1 + lbits;
+                put(kRecLit, 1, c, 1);
+                continue;
+            }
+
+            uint32_t b2 = bb << 1, n2 = nb - 1, used = 0;
+            const int sym = read_symbol(b2, n2, used);
+            if (sym < 0) break;
+            b2 <<= used;
+            n2 -= used;
+
+            if (sym == kSymFlush) {  // decompressor.c:501-514
+                bb = b2 << (n2 & 7);
+                nb = n2 & ~7u;
+                if (dreset && last_flush) fallback = true;  // dictionary reset inside the stream: lane / wave decoders
+                last_flush = true;
+                continue;
+            }
+            last_flush = false;
+
+            if (extended && sym >= kSymRle) {
+                bb = b2;  // symbol bits are committed before the payload is read (decompressor.c:521-526)
+                nb = n2;
+                const uint32_t trailing = (sym == kSymRle) ? 4u : 3u;
+                uint32_t value = 0, match_len = 0, off = 0;
+                int got = 0;
+                bool starved = false;
+                for (;;) {  // decode_rle / decode_extended_match with the loop's refill-and-retry (:114-273,447-456)
+                    if (got == 0) {
+                        uint32_t u3 = 0;
+                        int hsym = (nb >= 1 + trailing) ? read_symbol(bb, nb, u3) : -1;
+                        if (hsym >= 0 && nb - u3 < trailing) hsym = -1;
+                        if (hsym >= 0) {
+                            uint32_t b3 = bb << u3;
+                            value = ((uint32_t)hsym << trailing) + (b3 >> (32 - trailing));
+                            bb = b3 << trailing;
+                            nb -= u3 + trailing;
+                            got = (sym == kSymRle) ? 2 : 1;
+                            if (sym == kSymExt) match_len = value + minp + 12;
+                        }
+                    }
+                    if (got == 1 && nb >= wbits) {
+                        off = bb >> (32 - wbits);
+                        bb <<= wbits;
+                        nb -= wbits;
+                        got = 2;
+                    }
+                    if (got == 2) break;
+                    const uint32_t before = nb;
+                    refill();
+                    if (nb == before && ip == n) { starved = true; break; }
+                }
+                if (starved) break;
+                const uint32_t wp = V & mask, room = cap - op;
+                if (sym == kSymRle) {  // decompressor.c:140-173
+                    const uint32_t count = value + 2;
+                    const uint32_t w = count <= room ? count : room;
+                    put(kRecFill, w, 0, min(w, min(min(count, kRleWindowMax), W - wp)));
+                    if (w < count) { res = kOutputFull; break; }
+                } else {  // decompressor.c:229-272
+                    if (off >= W || off + match_len > W) { res = kOob; break; }
+                    const uint32_t w = match_len <= room ? match_len : room;
+                    put(kRecCopyExt, w, off, min(w, W - wp));  // up to the end of the buffer, no wrap
+                    if (w < match_len) { res = kOutputFull; break; }
+                }
+                continue;
+            }
+
+            // plain match, decompressor.c:529-572
+            if (n2 < wbits) break;
+            const uint32_t match_len = (uint32_t)sym + minp;
+            const uint32_t off = b2 >> (32 - wbits);
+            if (off >= W || off + match_len > W) { res = kOob; break; }
+            const uint32_t room = cap - op;
+            if (match_len > room) {  // partial copy, token not consumed (decompressor.c:553-557)
+                put(kRecCopy, room, off, room);
+                res = kOutputFull;
+                break;
+            }
+            bb = b2 << wbits;
+            nb = n2 - wbits;
+            put(kRecCopy, match_len, off, match_len);
+        }
+        if (!resume) break;
+        }  // fast / exact alternation
+    } while (false);
+
+    if (!live) return;
+    if (ntok > 0xFFFFFu || op > 0xFFFFu) fallback = true;
+    a.out_len[s] = op;
+    a.status[s] = (int8_t)res;
+    if (a.in_consumed) a.in_consumed[s] = ip;
+    sa.meta[k] = (ntok & 0xFFFFFu) | ((wbits - 8) << 20) | (dict_sel << 23) | ((nlag < 63 ? nlag : 63u) << 25) | (fallback ? kMetaFallback : 0u);
+    sa.flagged[s] = fallback ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RESOLVE: records -> one pointer per output byte -> pointer jumping -> bytes
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DecompressArgs& a = sa.d;
+    const uint32_t k = blockIdx.x;
+    const uint32_t s = sa.first + k;
+    const uint32_t meta = sa.meta[k];
+    if (meta & kMetaFallback) return;  // decoded by the lane / wave decoders afterwards
+    const uint32_t n_out = a.out_len[s];
+    if (n_out == 0) return;
+    const uint32_t ntok = meta & 0xFFFFFu, wbits = 8 + ((meta >> 20) & 7), dict_sel = (meta >> 23) & 3, nlag = (meta >> 25) & 63;
+    const uint32_t W = 1u << wbits, mask = W - 1;
+    const uint8_t* const dict = dict_sel == 3 ? a.dict : a.seed_dicts + ((size_t)dict_sel << 15);
+    const uint32_t* const rec = sa.recs + (size_t)k * sa.tokcap;
+
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, nt = blockDim.x;
+    const uint32_t capa = align_up(sa.maxcap, 16);
+    uint8_t* const outb = smem;                                             // capa bytes (+16)
+    uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);    // capa entries: src[p] == p <=> outb[p] is final
+    uint32_t* const lagl = reinterpret_cast<uint32_t*>(smem + capa + 16 + 2 * capa);  // kSplitMaxLag x 2
+    volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(lagl + 2 * kSplitMaxLag);  // 16 words
+
+    for (uint32_t i = tid; i < 2 * nlag; i += nt) lagl[i] = sa.lag[(size_t)k * kSplitMaxLag * 2 + i];
+    __syncthreads();
+
+    // lag before the token that starts at output position O (all lagging tokens that END at or before O)
+    auto lag_before_out = [&](uint32_t O) -> uint32_t {
+        uint32_t L = 0;
+        for (uint32_t i = 0; i < nlag; i++) {
+            if ((lagl[2 * i] & 0xFFFFu) <= O) L = lagl[2 * i + 1];
+        }
+        return L;
+    };
+    // output position of the byte with virtual position v (v >= 0): v + the lag of the lagging tokens written before it
+    auto out_of_virtual = [&](uint32_t v) -> uint32_t {
+        uint32_t L = 0;
+        for (uint32_t i = 0; i < nlag; i++) {
+            if ((lagl[2 * i] >> 16) <= v) L = lagl[2 * i + 1];
+        }
+        return v + L;
+    };
+    // ---- expansion, parallel over the bytes ----
+    // Token pass: the records' sizes are prefix-summed (256 tokens per step) and every token leaves its number + 1 at the
+    // output position where it starts (in `src`, which holds nothing else yet).  Byte pass: every thread takes 16
+    // consecutive output bytes; the token of its first byte is the last mark at or before it (a max-scan over the
+    // threads), the marks inside its own 16 entries switch tokens on the way.  Each byte becomes either a final byte
+    // (literal, dictionary) or a pointer to an earlier output byte.
+    for (uint32_t i = tid; i < capa / 2; i += nt) reinterpret_cast<uint32_t*>(src)[i] = 0;
+    __syncthreads();
+    {
+        uint32_t base = 0;  // output position of the step's first token (uniform)
+        for (uint32_t c0 = 0, par = 0; c0 < ntok; c0 += nt, par ^= 4) {
+            const uint32_t j = c0 + tid;
+            const uint32_t r = j < ntok ? rec[j] : 0u;
+            const uint32_t olen = (r >> 2) & 0xFFu;
+            uint32_t incl = olen;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= (uint32_t)off) incl += o;
+            }
+            if (lane == kWave - 1) ctl[par + wave] = incl;  // (two sets of partial sums: one barrier per step)
+            __syncthreads();
+            uint32_t O = base + incl - olen, total = 0;
+            for (uint32_t w2 = 0; w2 < (nt >> 6); w2++) {
+                const uint32_t t = ctl[par + w2];
+                if (w2 < wave) O += t;
+                total += t;
+            }
+            if (olen) src[O] = (uint16_t)(j + 1);
+            base += total;
+        }
+    }
+    __syncthreads();
+    for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += 16 * nt) {  // 4,096 bytes per round
+        const uint32_t p0 = r0 + 16 * tid;
+        uint32_t h[8];  // this thread's 16 marks
+        {
+            uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+            if (p0 < capa) lo = *reinterpret_cast<const uint4*>(src + p0), hi = *reinterpret_cast<const uint4*>(src + p0 + 8);
+            h[0] = lo.x, h[1] = lo.y, h[2] = lo.z, h[3] = lo.w, h[4] = hi.x, h[5] = hi.y, h[6] = hi.z, h[7] = hi.w;
+        }
+        uint32_t last = 0;  // position + 1 of this thread's last mark
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++)
+            if ((h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) last = p0 + i + 1;
+        uint32_t inc = last;  // inclusive max-scan over the wave
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= (uint32_t)off) inc = max(inc, o);
+        }
+        if (lane == kWave - 1) ctl[8 + wave] = inc;
+        __syncthreads();
+        uint32_t head = (uint32_t)__shfl_up((int)inc, 1);  // last mark in front of this thread's bytes (position + 1)
+        if (lane == 0) head = 0;
+        for (uint32_t w2 = 0; w2 < wave; w2++) head = max(head, (uint32_t)ctl[8 + w2]);
+        const uint32_t carry_in = carry;
+        head = max(head, carry);
+        uint32_t wgmax = carry;
+        for (uint32_t w2 = 0; w2 < (nt >> 6); w2++) wgmax = max(wgmax, (uint32_t)ctl[8 + w2]);
+        carry = wgmax;
+        // token of the byte in front of p0 (it spans into p0 unless p0 is marked).  Marks of earlier rounds have been
+        // overwritten with pointers: the last token of the previous round was handed over in ctl[12].
+        uint32_t jcur = 0;
+        if (head) jcur = (head == carry_in && r0) ? (uint32_t)ctl[12] : (uint32_t)src[head - 1] - 1u;
+        uint32_t hpos = head ? head - 1 : 0u;
+        __syncthreads();  // every mark has been read: `src` may be overwritten with pointers now
+        if (p0 < n_out) {
+            uint32_t sv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ob[4] = {0, 0, 0, 0};
+            uint32_t kind = 0, arg = 0, Vj = 0;
+            bool have = false;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t p = p0 + i;
+                const uint32_t m = (h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                if (m) jcur = m - 1, hpos = p, have = false;
+                if (p < n_out) {
+                    if (!have) {  // (about five times per 16 bytes: the records sit in L1 / L2)
+                        const uint32_t r = rec[jcur];
+                        kind = r & 3u, arg = r >> 10;
+                        Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
+                        have = true;
+                    }
+                    uint32_t sp = p, byte = 0;
+                    if (kind == kRecLit) {
+                        byte = arg;
+                    } else {
+                        const uint32_t idx = kind == kRecFill ? ((Vj - 1) & mask) : arg + (p - hpos);  // ring index read
+                        const uint32_t back = (Vj - 1 - idx) & mask;  // 0 = newest ... W-1 = oldest
+                        if (back >= Vj) {
+                            byte = dict[idx];  // never written: the dictionary
+                        } else {
+                            const uint32_t v = Vj - 1 - back;
+                            sp = nlag ? out_of_virtual(v) : v;
+                        }
+                    }
+                    sv[i >> 1] |= sp << (16 * (i & 1));
+                    ob[i >> 2] |= byte << (8 * (i & 3));
+                } else {
+                    sv[i >> 1] |= p << (16 * (i & 1));
+                }
+            }
+            *reinterpret_cast<uint4*>(src + p0) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+            *reinterpret_cast<uint4*>(src + p0 + 8) = make_uint4(sv[4], sv[5], sv[6], sv[7]);
+            *reinterpret_cast<uint4*>(outb + p0) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+            if (tid == nt - 1) ctl[12] = jcur;  // the token that reaches the end of this round
+        }
+        __syncthreads();
+    }
+
+#ifndef TAMP_SPLIT_NOJUMP
+    for (uint32_t round = 0; round < 17; round++) {
+        uint32_t pending = 0;
+        for (uint32_t p = tid; p < n_out; p += nt) {
+            const uint32_t s1 = src[p];
+            if (s1 != p) {
+                const uint32_t s2 = src[s1];
+                // (program order matters twice: the byte is read after its "final" mark was seen, and written before
+                // this position's own mark -- the LDS serves every wave's operations in order)
+                asm volatile("" ::: "memory");
+                if (s2 == s1) {
+                    outb[p] = outb[s1];
+                    asm volatile("" ::: "memory");
+                    src[p] = (uint16_t)p;
+                } else {
+                    src[p] = (uint16_t)s2;
+                    pending = 1;
+                }
+            }
+        }
+        if (!__syncthreads_or((int)pending)) break;
+    }
+#endif
+
+    // ---- out: aligned dwords, byte head / tail ----
+    uint8_t* const out = a.out + a.out_off[s];
+    const uint32_t head = min((uint32_t)((4 - (reinterpret_cast<uintptr_t>(out) & 3)) & 3), n_out);
+    if (tid < head) out[tid] = outb[tid];
+    const uint32_t ndw = (n_out - head) >> 2;
+    uint32_t* const out32 = reinterpret_cast<uint32_t*>(out + head);
+    for (uint32_t i = tid; i < ndw; i += nt) out32[i] = lds_u32_unaligned(outb, head + 4 * i);
+    for (uint32_t i = head + 4 * ndw + tid; i < n_out; i += nt) out[i] = outb[i];
+}
+
+}  // namespace tamp_amd

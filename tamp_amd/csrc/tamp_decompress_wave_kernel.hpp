@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) tamp_decompress_wave_kernel(DecompressArg
 
     const uint32_t gw = blockIdx.x * nwaves + wave, tw = gridDim.x * nwaves;
     for (uint32_t s = gw; s < a.n_streams; s += tw) {
+        if (a.only_flagged && !a.only_flagged[s]) continue;  // (wave-uniform)
         const uint8_t* const in = a.in + a.in_off[s];
         const uint32_t n = a.in_len[s];
         uint8_t* const out = a.out + a.out_off[s];

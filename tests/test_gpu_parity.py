@@ -616,7 +616,7 @@ def test_decoder_variants_long_streams(ta, oracle, monkeypatch):
     # truncated inputs
     for comp, d in list(cases[:12]):
         cases.append((comp[: rng.randrange(40, len(comp))], d))
-    for mode in ("wave", "lane", "global"):
+    for mode in ("wave", "lane", "global", "split"):
         monkeypatch.setenv("TAMP_AMD_DECODER", mode)
         for d in (None, d10):
             group = [c for c, dd in cases if dd is d]

@@ -219,7 +219,7 @@ def test_decoder_rejects_streams_the_bit_counters_cannot_hold(ta):
     data[big : big + len(good)] = torch.frombuffer(bytearray(good), dtype=torch.uint8).to(dev)
     in_off = torch.tensor([0, big], dtype=torch.int64, device=dev)
     in_len = torch.tensor([big, len(good)], dtype=torch.int32, device=dev)
-    for mode in ("wave", "lane", "global"):
+    for mode in ("wave", "lane", "global", "split"):
         os.environ["TAMP_AMD_DECODER"] = mode
         try:
             r = ta.decompress_batch(data, in_off, in_len.view(torch.int32), out_cap=64)

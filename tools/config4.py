@@ -30,7 +30,7 @@ for w, (ids, rows, r) in parts.items():
     del rep, within
 torch.cuda.synchronize()
 cap = torch.full((n,), L + 8, dtype=torch.int32, device=dev)
-for mode in ('wave', 'auto'):
+for mode in ('wave', 'global', 'split', 'auto'):
     if mode == 'auto': os.environ.pop('TAMP_AMD_DECODER', None)
     else: os.environ['TAMP_AMD_DECODER'] = mode
     ms = []

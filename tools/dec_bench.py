@@ -14,7 +14,7 @@ def run(name, rows, **kw):
     data = torch.from_numpy(rows.reshape(-1)).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
     r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=L, **kw)
     cap = torch.full((n,), L, dtype=torch.int32, device=dev)
-    for mode in ('wave', 'lane', 'global', 'auto'):
+    for mode in ('wave', 'lane', 'global', 'split', 'auto'):
         os.environ['TAMP_AMD_DECODER'] = mode
         if mode == 'auto': del os.environ['TAMP_AMD_DECODER']
         ms = []

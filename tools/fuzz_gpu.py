@@ -68,7 +68,7 @@ while time.time() - t0 < budget:
     trunc = rng.random() < 0.3
     if trunc:
         comp = [c[: rng.randrange(0, len(c) + 1)] for c in comp]
-    for mode in ('wave', 'lane', 'global'):
+    for mode in ('wave', 'lane', 'global', 'split'):
         os.environ['TAMP_AMD_DECODER'] = mode
         res = tamp_amd.decompress_batch(comp, out_cap=cap, dictionary=d, max_window_bits=rng.choice([window, 15]))
         for i in range(n):
