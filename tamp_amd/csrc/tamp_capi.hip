@@ -382,7 +382,19 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         SplitArgs sa;
         sa.maxcap = max_out_cap;
         sa.tokcap = std::max<uint32_t>(16, (uint32_t)std::min<uint64_t>(max_out_cap, (uint64_t)longest_in * 8 / 6 + 8));
-        const size_t slice = std::min<size_t>(n_streams, (size_t)1 << 17);
+        sa.tokcap = (sa.tokcap + 15u) & ~15u;  // whole 64-byte groups of records per stream
+        // Streams per slice: 256 Ki = 4 parse waves per SIMD (measured on configs[3], 1 Mi streams: 2^17 29.4 ms, 2^18 25.4 ms,
+        // 2^19 26.4 ms; TAMP_AMD_SPLIT_SLICE_LOG2 overrides), less when the scratch budget says so (records dominate:
+        // tokcap x 4 B per stream; TAMP_AMD_SPLIT_SCRATCH_MB, default 8 GiB of the 288 GB).
+        size_t slice_log2 = 18;
+        if (const char* e = getenv("TAMP_AMD_SPLIT_SLICE_LOG2")) { const int v = atoi(e); if (v >= 12 && v <= 22) slice_log2 = (size_t)v; }
+        size_t slice = std::min<size_t>(n_streams, (size_t)1 << slice_log2);
+        {
+            size_t budget = (size_t)8 << 30;
+            if (const char* e = getenv("TAMP_AMD_SPLIT_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
+            const size_t per = (size_t)sa.tokcap * 4 + 4 + kSplitMaxLag * 8;
+            slice = std::min(slice, std::max<size_t>(budget / per, 4096));
+        }
         const size_t b_recs = slice * sa.tokcap * 4, b_meta = slice * 4, b_lag = slice * kSplitMaxLag * 8;
         const size_t need = b_recs + b_meta + b_lag + n_streams + 64;
         uint8_t* base = nullptr;

@@ -61,7 +61,10 @@ struct SplitArgs {
 // ---------------------------------------------------------------------------------------------------------------
 // PARSE: the reference's token loop without the data (compare tamp_decompress_kernel.hpp, exact loop)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kParseRing = 64, kParseLane = 68;  // per lane: 64-byte input ring in LDS, odd dword stride
+// per lane in LDS: a 64-byte input ring and a stage of 20 records that leaves for HBM 16 records (64 bytes) at a time --
+// sixty-four lanes each storing one dword to a slot of its own cost the memory pipeline a transaction per lane and token
+// (the parse ran at a third of its instruction rate however many waves were resident); odd dword stride per lane
+constexpr uint32_t kParseRing = 64, kParseStage = 20, kParseLane = 64 + 4 * kParseStage + 4;
 __host__ __device__ constexpr uint32_t split_parse_lds(uint32_t threads) { return 128u + threads * kParseLane; }
 
 __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
@@ -88,6 +91,17 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
     uint32_t* const rec = sa.recs + (size_t)(live ? k : 0u) * sa.tokcap;
     uint32_t* const lag = sa.lag + (size_t)(live ? k : 0u) * kSplitMaxLag * 2;
     uint8_t* const inr = smem + 128 + threadIdx.x * kParseLane;
+    uint32_t* const rb = reinterpret_cast<uint32_t*>(inr + kParseRing);  // staged records
+    uint32_t nflushed = 0, nstage = 0;                                    // records in HBM / in the stage
+    auto flush16 = [&]() {  // the stage's first 16 records -> HBM as four 16-byte stores; the rest moves to the front
+        if (nflushed + 16 <= sa.tokcap) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) st16(reinterpret_cast<uint8_t*>(rec + nflushed + 4 * q), ld16(reinterpret_cast<const uint8_t*>(rb + 4 * q)));
+        }
+        nflushed += 16;
+        nstage -= 16;
+        for (uint32_t i = 0; i < nstage; i++) rb[i] = rb[16 + i];
+    };
     uint32_t ip = 0, op = 0, ntok = 0, nlag = 0, cumlag = 0;
     uint32_t V = 0;  // bytes written to the window so far (window_pos = V mod W on a fresh decoder)
     uint32_t wbits = 8, dict_sel = 2;
@@ -119,11 +133,9 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         // one record; `written` = bytes of it that enter the window
         auto put = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written) {
             if (olen == 0) return;
-            if (ntok >= sa.tokcap) {
-                fallback = true;
-            } else {
-                rec[ntok] = kind | (olen << 2) | (arg << 10);
-            }
+            if (ntok >= sa.tokcap) fallback = true;
+            rb[nstage++] = kind | (olen << 2) | (arg << 10);
+            if (nstage == kParseStage) flush16();
             ntok++;
             op += olen;
             V += written;
@@ -204,6 +216,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
             uint32_t step = 0;
             while (__ballot(fast)) {
                 if ((step++ & 3) == 0 && fast) {  // ---- I/O point ----
+                    if (nstage >= 16) flush16();
                     if (cb_valid && fill + 16 - (rp - 4) <= kParseRing) {
                         st16(inr + ((fill - sp0) & (kParseRing - 1)), cb);
                         if (fill == rp) wnext = cb.w[0];
@@ -402,6 +415,8 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
     } while (false);
 
     if (!live) return;
+    for (uint32_t i = 0; i < nstage; i++)
+        if (nflushed + i < sa.tokcap) rec[nflushed + i] = rb[i];
     if (ntok > 0xFFFFFu || op > 0xFFFFu) fallback = true;
     a.out_len[s] = op;
     a.status[s] = (int8_t)res;
@@ -461,31 +476,32 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     // (literal, dictionary) or a pointer to an earlier output byte.
     for (uint32_t i = tid; i < capa / 2; i += nt) reinterpret_cast<uint32_t*>(src)[i] = 0;
     __syncthreads();
-    {
-        uint32_t base = 0;  // output position of the step's first token (uniform)
-        for (uint32_t c0 = 0, par = 0; c0 < ntok; c0 += nt, par ^= 4) {
-            const uint32_t j = c0 + tid;
-            const uint32_t r = j < ntok ? rec[j] : 0u;
-            const uint32_t olen = (r >> 2) & 0xFFu;
-            uint32_t incl = olen;
+    {   // every thread takes a run of consecutive tokens: one prefix sum over the workgroup
+        const uint32_t K = (ntok + nt - 1) / nt;
+        const uint32_t j0 = min(tid * K, ntok), j1 = min(j0 + K, ntok);
+        uint32_t sum = 0;
+        for (uint32_t j = j0; j < j1; j++) sum += (rec[j] >> 2) & 0xFFu;
+        uint32_t incl = sum;
 #pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= (uint32_t)off) incl += o;
-            }
-            if (lane == kWave - 1) ctl[par + wave] = incl;  // (two sets of partial sums: one barrier per step)
-            __syncthreads();
-            uint32_t O = base + incl - olen, total = 0;
-            for (uint32_t w2 = 0; w2 < (nt >> 6); w2++) {
-                const uint32_t t = ctl[par + w2];
-                if (w2 < wave) O += t;
-                total += t;
-            }
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        if (lane == kWave - 1) ctl[wave] = incl;
+        __syncthreads();
+        uint32_t O = incl - sum;
+        for (uint32_t w2 = 0; w2 < wave; w2++) O += ctl[w2];
+        for (uint32_t j = j0; j < j1; j++) {  // (the records come from L1 the second time)
+            const uint32_t olen = (rec[j] >> 2) & 0xFFu;
             if (olen) src[O] = (uint16_t)(j + 1);
-            base += total;
+            O += olen;
         }
     }
     __syncthreads();
+#if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 1
+    return;
+#endif
+    uint32_t um0 = 0, um1 = 0, um2 = 0, um3 = 0;  // this thread's bytes that still point elsewhere, one mask per round
     for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += 16 * nt) {  // 4,096 bytes per round
         const uint32_t p0 = r0 + 16 * tid;
         uint32_t h[8];  // this thread's 16 marks
@@ -521,54 +537,64 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         uint32_t hpos = head ? head - 1 : 0u;
         __syncthreads();  // every mark has been read: `src` may be overwritten with pointers now
         if (p0 < n_out) {
-            uint32_t sv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ob[4] = {0, 0, 0, 0};
-            uint32_t kind = 0, arg = 0, Vj = 0;
+            // (a rolled loop over the thread's own LDS entries: unrolled over register copies it was 1,700 VALU
+            // instructions of straight-line code for the 16 bytes)
+            uint32_t kind = 0, arg = 0, Vj = 0, um = 0;
             bool have = false;
-#pragma unroll
-            for (uint32_t i = 0; i < 16; i++) {
-                const uint32_t p = p0 + i;
-                const uint32_t m = (h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            const uint32_t pend = min(p0 + 16, n_out);
+#pragma unroll 1
+            for (uint32_t p = p0; p < pend; p++) {
+                const uint32_t m = src[p];
                 if (m) jcur = m - 1, hpos = p, have = false;
-                if (p < n_out) {
-                    if (!have) {  // (about five times per 16 bytes: the records sit in L1 / L2)
-                        const uint32_t r = rec[jcur];
-                        kind = r & 3u, arg = r >> 10;
-                        Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
-                        have = true;
-                    }
-                    uint32_t sp = p, byte = 0;
-                    if (kind == kRecLit) {
-                        byte = arg;
-                    } else {
-                        const uint32_t idx = kind == kRecFill ? ((Vj - 1) & mask) : arg + (p - hpos);  // ring index read
-                        const uint32_t back = (Vj - 1 - idx) & mask;  // 0 = newest ... W-1 = oldest
-                        if (back >= Vj) {
-                            byte = dict[idx];  // never written: the dictionary
-                        } else {
-                            const uint32_t v = Vj - 1 - back;
-                            sp = nlag ? out_of_virtual(v) : v;
-                        }
-                    }
-                    sv[i >> 1] |= sp << (16 * (i & 1));
-                    ob[i >> 2] |= byte << (8 * (i & 3));
-                } else {
-                    sv[i >> 1] |= p << (16 * (i & 1));
+                if (!have) {  // (about five times per 16 bytes: the records sit in L1 / L2)
+                    const uint32_t r = rec[jcur];
+                    kind = r & 3u, arg = r >> 10;
+                    Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
+                    have = true;
                 }
+                uint32_t sp = p, byte = 0;
+                if (kind == kRecLit) {
+                    byte = arg;
+                } else {
+                    const uint32_t idx = kind == kRecFill ? ((Vj - 1) & mask) : arg + (p - hpos);  // ring index read
+                    const uint32_t back = (Vj - 1 - idx) & mask;  // 0 = newest ... W-1 = oldest
+                    if (back >= Vj) {
+                        byte = dict[idx];  // never written: the dictionary
+                    } else {
+                        const uint32_t v = Vj - 1 - back;
+                        sp = nlag ? out_of_virtual(v) : v;
+                    }
+                }
+                src[p] = (uint16_t)sp;
+                outb[p] = (uint8_t)byte;
+                um |= (sp != p ? 1u : 0u) << (p - p0);
             }
-            *reinterpret_cast<uint4*>(src + p0) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
-            *reinterpret_cast<uint4*>(src + p0 + 8) = make_uint4(sv[4], sv[5], sv[6], sv[7]);
-            *reinterpret_cast<uint4*>(outb + p0) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+            // (the thread that owns the last byte of a full round also sees the token that reaches its end)
             if (tid == nt - 1) ctl[12] = jcur;  // the token that reaches the end of this round
+            if (r0 == 0) um0 = um;
+            else if (r0 == 16 * nt) um1 = um;
+            else if (r0 == 32 * nt) um2 = um;
+            else um3 = um;
         }
         __syncthreads();
     }
 
-#ifndef TAMP_SPLIT_NOJUMP
+#if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 2
+    return;
+#endif
+    // ---- pointer jumping: every round halves the chains; a byte is final when it points at itself.  Each thread keeps
+    // working on its own bytes (the masks of the byte pass), so a round costs what is still unresolved. ----
+    static_assert(kSplitMaxOut <= 4 * 16 * 256, "four masks per thread");
     for (uint32_t round = 0; round < 17; round++) {
-        uint32_t pending = 0;
-        for (uint32_t p = tid; p < n_out; p += nt) {
-            const uint32_t s1 = src[p];
-            if (s1 != p) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            uint32_t um = q == 0 ? um0 : (q == 1 ? um1 : (q == 2 ? um2 : um3));
+            const uint32_t p0 = (q * nt + tid) * 16;
+            for (uint32_t m = um; m;) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t p = p0 + i;
+                const uint32_t s1 = src[p];
                 const uint32_t s2 = src[s1];
                 // (program order matters twice: the byte is read after its "final" mark was seen, and written before
                 // this position's own mark -- the LDS serves every wave's operations in order)
@@ -577,16 +603,22 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
                     outb[p] = outb[s1];
                     asm volatile("" ::: "memory");
                     src[p] = (uint16_t)p;
+                    um &= ~(1u << i);
                 } else {
                     src[p] = (uint16_t)s2;
-                    pending = 1;
                 }
             }
+            if (q == 0) um0 = um;
+            else if (q == 1) um1 = um;
+            else if (q == 2) um2 = um;
+            else um3 = um;
         }
-        if (!__syncthreads_or((int)pending)) break;
+        if (!__syncthreads_or((int)(um0 | um1 | um2 | um3))) break;
     }
-#endif
 
+#if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 3
+    return;
+#endif
     // ---- out: aligned dwords, byte head / tail ----
     uint8_t* const out = a.out + a.out_off[s];
     const uint32_t head = min((uint32_t)((4 - (reinterpret_cast<uintptr_t>(out) & 3)) & 3), n_out);
