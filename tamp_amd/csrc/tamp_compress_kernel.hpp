@@ -59,6 +59,7 @@ struct CompressArgs {
     uint8_t* state;     // per stream: (1 << wbits) window bytes in ring order, then u16 window_pos, then u8 token-written flag
     uint32_t* work_counter;    // TAMP_STREAM_LOOP builds: next stream index to hand out (zeroed before the launch)
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
+    uint32_t cut_run;          // epoch cut: a run of this many aligned dwords of one byte ends the block (0 = off)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
 };
 
@@ -510,7 +511,7 @@ struct Walk {
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
 enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
 // ctl words
-enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14 };
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14, cCut = 15 };
 
 #ifdef TAMP_PROF
 #define TAMP_PROF_MARK(i)                                     \
@@ -652,8 +653,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             asm volatile("" : "+v"(tid));
             lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
             const uint32_t left = n - e_p0;
-            const uint32_t nvalid = left < cur_blk ? left : cur_blk;
-            const uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
+            // positions this epoch matches: the block, or less when a long run of one byte cuts it short (below; the walk's
+            // later passes over the same tables read the figure back)
+            uint32_t nvalid = left < cur_blk ? left : cur_blk;
+            if (!need_match) nvalid = Walk::uni(ctl[cCut]);
+            uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
             const uint8_t* const steps = LAZY ? vstep : blen;
             if (need_match) {
                 // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 for (uint32_t k = tid; k < kHashBuckets / 2; k += nt) cntw[k] = 0;
-                for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a_blk + 128; k += nt) blen[k] = 0x80;  // sentinels
+                if (tid == 0) ctl[cCut] = 0xFFFFFFFFu;
                 __syncthreads();
                 TAMP_PROF_MARK(0);
 #ifdef TAMP_PROF
@@ -682,22 +686,42 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 // ---------------- index: counting sort of buffer positions by bigram ----------------
                 asm volatile("" : "+v"(tid));
                 lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
-                const uint32_t NE = nvalid ? W + nvalid : 0;  // positions 0..NE-1 (every query's own bigram included)
-                for (uint32_t c4 = tid * 4; c4 < NE; c4 += nt * 4) {
+                const uint32_t NE0 = nvalid ? W + nvalid : 0;  // positions 0..NE0-1 (every query's own bigram included)
+                const uint32_t cut_run = a.cut_run;
+                for (uint32_t c4 = tid * 4; c4 < NE0; c4 += nt * 4) {
                     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
                     const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
-                    // RUNS builds: any run of 7+ bytes holds an aligned dword of four equal bytes; epochs without one
-                    // skip the run search
-                    if constexpr (RUNS) { if (d0 == (d0 & 0xFFu) * 0x01010101u) ctl[cQuad] = 1; }
+                    if (d0 == (d0 & 0xFFu) * 0x01010101u) {
+                        // RUNS builds: any run of 7+ bytes holds an aligned dword of four equal bytes; epochs without one
+                        // skip the run search
+                        if constexpr (RUNS) ctl[cQuad] = 1;
+                        // Epoch cut.  In the extended format a long run of one byte ahead of the walk nearly always
+                        // becomes an RLE token that writes 8 bytes for all it consumes (compressor.c:342-359): what was
+                        // matched behind it under "everything consumed is written" is thrown away.  The first run of
+                        // `cut_run` aligned dwords among this epoch's new positions therefore ends the block just inside
+                        // it; the next epoch starts where the walk comes out of the run.  (A guess about cost only: a
+                        // match that covers the run after all leaves the walk at the end of a shorter block.)
+                        if (cut_run && d1 == d0 && c4 >= W + e_pending + 4 && c4 + 4 * cut_run <= NE0) {
+                            bool all = true;
+                            for (uint32_t k = 2; k < cut_run; k++) all = all && *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4 * k) == d0;
+                            if (all) atomicMin(const_cast<uint32_t*>(&ctl[cCut]), c4);
+                        }
+                    }
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
-                        if (c4 + j < NE) {
+                        if (c4 + j < NE0) {
                             const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRemBits;
                             atomicAdd(&cntw[h >> 1], 1u << ((h & 1) * 16));
                         }
                     }
                 }
                 __syncthreads();
+                {
+                    const uint32_t cutc = Walk::uni(ctl[cCut]);
+                    if (cutc < NE0) nvalid = cutc - W + 4, nv = LAZY ? 2 * nvalid : nvalid;
+                }
+                const uint32_t NE = nvalid ? W + nvalid : 0;  // positions the index lists (the counts above are upper bounds)
+                for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a_blk + 128; k += nt) blen[k] = 0x80;  // sentinels
                 uint32_t nruns = 0;  // listed runs of this epoch (RUNS builds)
                 if constexpr (RUNS) {
                     if (Walk::uni(ctl[cQuad])) {
@@ -804,6 +828,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 // Order the queries by scan length (counting sort, longest first) so that the 64 lanes of a wave
                 // loop about equally often: the greedy per-lane scan is otherwise paced by its longest bucket.
                 if (tid < 64) bins[tid] = 0;
+                if (tid == 0) ctl[cCut] = nvalid;  // (everybody has read the cut position: several barriers back)
                 __syncthreads();
                 for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
                     const uint32_t Lq = min((uint32_t)bidx[q] - (uint32_t)qstart[q], 63u);

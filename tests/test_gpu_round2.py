@@ -464,3 +464,51 @@ def test_command_line_round_trip(ta, oracle, tmp_path):
     empty.write_bytes(b"")
     r = run("compress", "-i", str(empty))
     assert r.returncode == 1 and b"No data provided." in r.stderr
+
+
+# --------------------------------------------------------------------------------------------------------------
+# epoch cut at long runs of one byte (tamp_compress_kernel.hpp: the block ends just inside the first such run)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("window,slen", [(8, 256), (8, 700), (10, 4096), (12, 6000)])
+def test_long_runs_anywhere_in_the_block_match_oracle(ta, oracle, monkeypatch, window, slen):
+    """Text with runs of 30..300 equal bytes dropped at random places (several per stream, some back to back, some at
+    the very start / end, some repeated so that a match can cover them): extended format, run-cut threshold at its
+    default, at its smallest and off -- the bytes may not depend on it."""
+    import torch
+    from tamp_amd import workloads as wl
+
+    rng = np.random.default_rng(window * 1000 + slen)
+    n = 384
+    rows = wl.synth_text(n, slen, first_index=77).copy()
+    for i in range(n):
+        k = int(rng.integers(0, 5))
+        for _ in range(k):
+            ln = int(rng.integers(30, 300))
+            at = int(rng.integers(0, slen))
+            if rng.random() < 0.15:
+                at = 0
+            if rng.random() < 0.15:
+                at = max(0, slen - ln)
+            rows[i, at : at + ln] = rng.choice([0x20, 0x00, 0x3D, 0x61])
+        if i % 7 == 0 and slen >= 700:  # the same run + tail twice: the second one can be matched instead of run-coded
+            rows[i, 300:360] = 0x2D
+            rows[i, 360:380] = rows[i, 100:120]
+            rows[i, 500:560] = 0x2D
+            rows[i, 560:580] = rows[i, 100:120]
+    off, ln_ = wl.csr_for_fixed(n, slen)
+    dev = torch.device("cuda", 0)
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+    len_t = torch.from_numpy(ln_.astype(np.int32)).to(dev)
+    want = oracle.compress_batch(rows.reshape(-1), off, ln_, window=window, literal=8, extended=True, threads=8)
+    for cut in (None, "2", "0"):
+        if cut is None:
+            monkeypatch.delenv("TAMP_AMD_CUT_RUN", raising=False)
+        else:
+            monkeypatch.setenv("TAMP_AMD_CUT_RUN", cut)
+        for runs in ("0", "1"):
+            monkeypatch.setenv("TAMP_AMD_RUNS", runs)
+            r = ta.compress_batch(data, off_t, len_t, window=window, literal=8, extended=True, max_in_len=slen)
+            gs = _streams_of(r, n)
+            for i in range(n):
+                assert gs[i] == want.stream(i), (cut, runs, i)
