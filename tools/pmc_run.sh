@@ -18,7 +18,14 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CON
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec4_stats -- python tools/config4.py > $OUT/dec4_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o dec4_fetch -- python tools/config4.py > $OUT/dec4_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o dec4_write -- python tools/config4.py > $OUT/dec4_write.log 2>&1
-# ---- decoders on the bench batch (65,536 x 4 KiB, w=10), all three ----
+# ---- split decoder on the bench batch: instruction counters per kernel ----
+N=65536 bash tools/dec_split_pmc.sh > $OUT/dec_split_pmc.log 2>&1
+cp gpurun_out/sp/p_counter_collection.csv $OUT/dec_split_sq_counter_collection.csv 2>/dev/null
+cp gpurun_out/sp/s_kernel_stats.csv $OUT/dec_split_kernel_stats.csv 2>/dev/null
+# ---- BASELINE configs[4] share and 256-byte messages without padding ----
+python tools/config5.py > $OUT/config5.log 2>&1
+python tools/short_msgs.py 1048576 > $OUT/short_msgs.log 2>&1
+# ---- decoders on the bench batch (65,536 x 4 KiB, w=10), all four ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec2_stats -- python tools/dec_bench.py > $OUT/dec2_stats.log 2>&1
 # ---- real text, both formats ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o realtext_stats -- python tools/realtext.py > $OUT/realtext_stats.log 2>&1
@@ -36,4 +43,4 @@ for f in sorted(glob.glob('$OUT/*_kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         if 'tamp' in r['Name']: print(f.split('/')[-1], r['Name'][:70], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
 PY
-grep -h "GB/s" $OUT/dec4_stats.log $OUT/dec2_stats.log $OUT/realtext_stats.log
+grep -h "GB/s\|per stream" $OUT/dec4_stats.log $OUT/dec2_stats.log $OUT/realtext_stats.log $OUT/config5.log $OUT/short_msgs.log $OUT/dec_split_pmc.log

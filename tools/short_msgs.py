@@ -3,7 +3,11 @@
    to back, cut at 256 bytes).  A sample of each is compared with the oracle.  usage: python tools/short_msgs.py [n]"""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
-import numpy as np, torch, tamp_amd
+import numpy as np, torch
+from tamp_amd import _lib
+if os.environ.get('TAMP_VAR'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libtamp_var%s.so' % os.environ['TAMP_VAR'])
+import tamp_amd
 from tamp_amd import workloads as wl
 from oracle.checker import Oracle
 dev = torch.device('cuda:0')
