@@ -277,6 +277,10 @@ def main():
             also["real_text"] = also_real_text(args, torch, np)
         except Exception as e:
             also["real_text"] = {"error": repr(e)[:200]}
+        try:
+            also["baseline_configs"] = also_baseline_configs(torch, np)
+        except Exception as e:  # noqa: BLE001 -- the headline line must not die for a side measurement
+            also["baseline_configs"] = {"error": repr(e)[:200]}
         result["also"] = also
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -431,6 +435,76 @@ def also_real_text(args, torch, np):
             entry[tag + "_ratio"] = round(float(r.out_len.to(torch.int64).sum().item()) / (n * L), 4)
             entry[tag + "_parity_first_512"] = "bit-exact" if ok else "MISMATCH"
         out[name] = entry
+    return out
+
+
+def also_baseline_configs(torch, np):
+    """BASELINE configs[3] and configs[4] at a size that fits the bench's time budget (the full sizes run in
+    tests/test_gpu_round2.py and tools/config4.py / config5.py): decode of 262,144 pre-compressed 4 KiB streams with
+    windows 2^8..2^12 interleaved, and compress of 1,048,576 256-byte telemetry messages with the shared custom
+    dictionary (w=8 l=7 extended); both are checked by decoding back to the input."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda", 0)
+    out = {}
+    # ---- configs[3]: the streams are produced by this library's compressor, per window, and laid out as one slab
+    n, L = 262144, 4096
+    base = wl.synth_text(n // 5 + 1, L, first_index=1 << 20)
+    wsel = torch.arange(n, device=dev) % 5 + 8
+    olen = torch.zeros(n, dtype=torch.int64, device=dev)
+    parts = {}
+    for w in range(8, 13):
+        ids = torch.nonzero(wsel == w).flatten()
+        rows = base[: len(ids)]
+        off, ln = wl.csr_for_fixed(len(ids), L)
+        r = tamp_amd.compress_batch(torch.from_numpy(rows.reshape(-1)).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev),
+                                    torch.from_numpy(ln.astype(np.int32)).to(dev), window=w, max_in_len=L)
+        parts[w] = (ids, r)
+        olen[ids] = r.out_len.to(torch.int64)
+    in_off = torch.cumsum(olen, 0) - olen
+    slab = torch.empty(int(olen.sum().item()) + 64, dtype=torch.uint8, device=dev)
+    for w, (ids, r) in parts.items():
+        lens = r.out_len.to(torch.int64)
+        rep = torch.repeat_interleave(torch.arange(len(ids), device=dev), lens)
+        within = torch.arange(int(lens.sum().item()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        slab[in_off[ids][rep] + within] = r.out[r.out_off.to(torch.int64)[rep] + within]
+        del rep, within
+    ms, d = [], None
+    for _ in range(3):
+        d = tamp_amd.decompress_batch(slab, in_off, olen.to(torch.int32), out_cap=L + 8, timing=True)
+        ms.append(float(d.kernel_ms))
+    ok = bool((d.status == 2).all().item()) and bool((d.out_len == L).all().item())
+    got = d.out.view(-1)[: n * (L + 8)].view(n, L + 8)
+    for w, (ids, r) in parts.items():
+        k = min(256, len(ids))
+        ok = ok and bool(torch.equal(got[ids[:k], :L].cpu(), torch.from_numpy(base[:k])))
+    comp = int(olen.sum().item())
+    out["configs[3] decode"] = {"streams": n, "stream_len": L, "windows": "2^8..2^12 interleaved", "kernel_ms": round(min(ms), 3),
+                                "output_GBps": round(n * L / (min(ms) * 1e-3) / 1e9, 1),
+                                "algorithmic_GBps": round((comp + n * L) / (min(ms) * 1e-3) / 1e9, 1),
+                                "round_trip_sample": "equal" if ok else "MISMATCH"}
+    del slab, d, got, parts
+    # ---- configs[4]: one GPU's share is 2,097,152 messages; half of it here
+    n, L = 1 << 20, 256
+    dic = wl.telemetry_dictionary(bytes(tamp_amd.initialize_dictionary(256, literal=7)))
+    rows = wl.telemetry(n, L)
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off_t = torch.arange(n, dtype=torch.int64, device=dev) * L
+    len_t = torch.full((n,), L, dtype=torch.int32, device=dev)
+    ms, r = [], None
+    for _ in range(3):
+        r = tamp_amd.compress_batch(data, off_t, len_t, window=8, literal=7, dictionary=dic, max_in_len=L, timing=True)
+        ms.append(float(r.kernel_ms))
+    back = tamp_amd.decompress_batch(r.out, r.out_off, r.out_len, out_cap=L + 8, dictionary=dic, timing=True)
+    got = back.out.view(-1)[: n * (L + 8)].view(n, L + 8)[:, :L]
+    ok = bool((r.status == 0).all().item()) and bool((back.out_len == L).all().item()) and bool(torch.equal(got, data.view(n, L)))
+    out["configs[4] compress"] = {"messages": n, "message_len": L, "conf": "window=8 literal=7 extended=1, shared custom dictionary",
+                                  "kernel_ms": round(min(ms), 3), "input_GBps": round(n * L / (min(ms) * 1e-3) / 1e9, 1),
+                                  "messages_per_s": round(n / (min(ms) * 1e-3)),
+                                  "ratio": round(float(r.out_len.to(torch.int64).sum().item()) / (n * L), 4),
+                                  "decode_output_GBps": round(n * L / (float(back.kernel_ms) * 1e-3) / 1e9, 1),
+                                  "round_trip": "equal" if ok else "MISMATCH"}
     return out
 
 
