@@ -101,7 +101,7 @@ struct CompressLds {
         obuf = o;
         o += align_up(obuf_words * 4, 16);
         ctl = o;
-        o += 64 + 64 * 4 + 16;  // control words + 64 sort bins + the 15 prefix codes as a byte table
+        o += 80 + 64 * 4 + 16;  // 20 control words + 64 sort bins + the 15 prefix codes as a byte table
         // RUNS builds: the long runs of the epoch buffer (start | end << 16) and one bit per buffer position that
         // is left out of the bigram index (the interior of a listed run)
         runs = o;
@@ -202,6 +202,7 @@ struct Walk {
     uint32_t rle_count, ext_count, ext_pos;
     bool ext_resolved;
     bool last_ext_direct = false;  // (instrumented builds)
+    uint32_t dbg_lag_rle = 0, dbg_lag_ext = 0, dbg_lag_rle_short = 0;  // (instrumented builds)
     uint32_t ntok, ns;
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
@@ -280,6 +281,9 @@ struct Walk {
         put_exthuff(count - 2, 4);
         uint32_t w = min(min(count, kRleWindowMax), W - wp());
         const bool clean = (wr + count == rd) && (w == count);
+#ifdef TAMP_PROF
+        if (w < count) { dbg_lag_rle++; if (count < 24) dbg_lag_rle_short++; }
+#endif
         append(w, clean, [&](uint32_t) { return sym; });
     }
 
@@ -291,6 +295,9 @@ struct Walk {
         put(pos, wbits);
         uint32_t w = min(count, W - wp());
         const bool clean = (wr + count == rd) && (w == count);
+#ifdef TAMP_PROF
+        if (w < count) dbg_lag_ext++;
+#endif
         const uint32_t wr0 = wr, wp0 = wp();
         // Sources are read in the pre-token window; appended bytes land beyond it (the memmove
         // semantics of tamp_window_copy, common.c:58-86, for free).
@@ -508,10 +515,14 @@ struct Walk {
     }
 };
 
+#ifndef TAMP_BRK_SHIFT  // block size after a break (tuning builds override)
+#define TAMP_BRK_SHIFT 1
+#define TAMP_BRK_MIN 512
+#endif
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
 enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
 // ctl words
-enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14, cCut = 15 };
+enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14, cCut = 15, cCutThr = 16 };
 
 #ifdef TAMP_PROF
 #define TAMP_PROF_MARK(i)                                     \
@@ -571,9 +582,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
     uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
     volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
-    uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 64);
+    uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 80);
     // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
-    uint8_t* const codetab = smem + L.ctl + 64 + 256;
+    uint8_t* const codetab = smem + L.ctl + 80 + 256;
     uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
     uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
 
@@ -632,6 +643,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         wk.wp_e = wp0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
         wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
+        if (tid_k == 0) ctl[cCutThr] = a.cut_run;  // (read after the load phase's barrier)
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
         // workgroup-uniform output state
@@ -687,7 +699,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 asm volatile("" : "+v"(tid));
                 lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
                 const uint32_t NE0 = nvalid ? W + nvalid : 0;  // positions 0..NE0-1 (every query's own bigram included)
-                const uint32_t cut_run = a.cut_run;
+                const uint32_t cut_run = Walk::uni(ctl[cCutThr]);  // (per stream: it adapts, see the walk's re-base)
                 for (uint32_t c4 = tid * 4; c4 < NE0; c4 += nt * 4) {
                     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ebuf + c4);
                     const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4);
@@ -1422,11 +1434,19 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     // written (oracle/tamp_model.c m_epoch_begin)
                     const uint32_t pending = wk.rle_count + wk.ext_count;
                     const uint32_t shift = wk.wr;
-                    // broke inside the block (lag) -> quarter it; ran off its end -> double it
+                    // broke inside the block (lag) -> halve it, 512 positions at least; ran off its end -> double it
+                    // (measured on 16,384 x 4 KiB: quarter / 256 prose 12.75, Python 5.72 GB/s; halve / 512: 13.64, 5.76; halve / 1024: 13.15,
+                    // 5.42; never shrink: 11.62, 4.81)
                     const bool broke = wk.wr + pending != wk.rd;  // bytes were consumed that will never be written
-                    uint32_t nb2 = broke ? max(cur_blk >> 2, 256u) : min(cur_blk << 1, a_blk);
+                    uint32_t nb2 = broke ? max(cur_blk >> TAMP_BRK_SHIFT, (uint32_t)TAMP_BRK_MIN) : min(cur_blk << 1, a_blk);
                     nb2 = min(nb2, a_blk);
                     if (lane == 0) ctl[cBlk] = nb2;
+                    // The cut was a guess: when the walk arrives at the end of a shortened block without a lag, a match
+                    // carried it through the run and the cut only cost an index build -- this stream's runs have to be
+                    // twice as long from now on.  (Source code: indentation repeats the line above; prose: rules and
+                    // table borders mostly do not.)
+                    if (nvalid < (left < cur_blk ? left : cur_blk) && !broke && wk.rd >= nvalid && lane == 0)
+                        ctl[cCutThr] = min(2u * (uint32_t)ctl[cCutThr], 64u);
                     wk.wp_e = wk.wp();
                     w_p0 += wk.rd - pending;
                     wk.wr = 0;
@@ -1635,8 +1655,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             __syncthreads();
         }
 #ifdef TAMP_PROF
-        if (tid == 0 && a.prof)
+        if (tid == 0 && a.prof) {
+            if (a.dbg & 0x1000u) pt[6] = wk.dbg_lag_rle, pt[7] = wk.dbg_lag_ext, pt[8] = wk.dbg_lag_rle_short;  // lag causes instead of the fine timers
             for (int i = 0; i < 16; i++) atomicAdd(&a.prof[i], pt[i]);
+        }
 #endif
         __syncthreads();  // ctl / LDS reuse by the next stream
     }
