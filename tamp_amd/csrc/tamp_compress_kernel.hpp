@@ -34,7 +34,10 @@ constexpr uint32_t kHashBits = 11;
 constexpr uint32_t kHashBuckets = 1u << kHashBits;
 constexpr uint32_t kRemBits = 16 - kHashBits;  // bigram bits not implied by the bucket number
 constexpr uint32_t kRunCap = 128;   // long runs listed per epoch (RUNS builds); further runs stay fully indexed
-constexpr uint32_t kLongRun = 8;    // a run of one byte this long is listed; its interior leaves the bigram index
+#ifndef TAMP_LONG_RUN
+#define TAMP_LONG_RUN 8
+#endif
+constexpr uint32_t kLongRun = TAMP_LONG_RUN;    // a run of one byte this long is listed; its interior leaves the bigram index
 constexpr uint32_t kSlowCap = 256;             // explicit (non-derivable) token pieces per walk segment
 
 struct CompressArgs {
@@ -1099,7 +1102,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     // are compared like any index entry and merged into the result of the first pass (each thread
                     // revisits its own queries).  Interior positions within 15 bytes of the newest window byte run into
                     // the oldest ones like their indexed neighbours (prefix_len_wrapped16).
+#ifdef TAMP_PROF
+                    if (nruns && !(a.dbg & 0x4000u)) {  // (0x4000: instruction-count experiments without the second pass)
+#else
                     if (nruns) {
+#endif
                         for (uint32_t j = tid; j < nq; j += nt) {
                             const uint32_t q = sorted[j];
                             const uint32_t b01 = lds_u32_unaligned(ebuf, W + q);
@@ -1164,7 +1171,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     const uint32_t c = m == 0 ? lo : (m == 1 ? cz : cs + (m - 2));
                                     if (c < lo || c > hi || (m && c == lo)) continue;
                                     const uint32_t lim_i = W - ((c + e_wp) & mask);
-                                    const uint32_t len = prefix_len16(ebuf, c, P);
+                                    // run remainder at the candidate against the pattern's leading run: the shorter one
+                                    // ends the match (its next byte is not x, the other side's is) -- only equal runs
+                                    // go on behind the run and need the bytes compared.  (A run capped at the end of
+                                    // the indexed range has 16+ bytes left at every candidate: min() is still right.)
+                                    const uint32_t rc = rb - c;
+                                    uint32_t len = min(rc, rq);
+                                    if (rc == rq) len = prefix_len16(ebuf, c, P);
                                     key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
                                 }
                             }
@@ -1315,7 +1328,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
                 uint32_t nqueued = 0;  // blocks whose tokens are still to be listed
                 uint32_t segv = 0;     // lane k: first position | first token slot << 16 of queued block k
+#ifdef TAMP_PROF
+                unsigned long long dbg_list = 0, dbg_hop = 0, dbg_calls = 0;
+#endif
                 auto list_queued = [&]() {
+#ifdef TAMP_PROF
+                    const unsigned long long lt0 = __builtin_readcyclecounter();
+                    dbg_calls++;
+#endif
                     __builtin_amdgcn_wave_barrier();
                     if ((uint32_t)lane < nqueued) {
                         uint32_t pp = segv & 0xFFFFu;
@@ -1331,6 +1351,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                     __builtin_amdgcn_wave_barrier();
                     nqueued = 0;
+#ifdef TAMP_PROF
+                    dbg_list += __builtin_readcyclecounter() - lt0;
+#endif
                 };
                 for (;;) {
                     if (wk.ntok + 72 > L.tokcap || wk.ns + 8 > kSlowCap) {
@@ -1347,6 +1370,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         // later, many blocks at a time (list_queued): a listing pass costs as many dependent LDS
                         // round trips as the fullest block has tokens, however few blocks it serves.
                         uint32_t total = 0, nhop = 0;
+#ifdef TAMP_PROF
+                        const unsigned long long ht0 = __builtin_readcyclecounter();
+#endif
                         while (pos < nv && nqueued < 64 && wk.ntok + total + 64 <= L.tokcap) {
                             uint32_t j, cpos;
                             if constexpr (LAZY) {
@@ -1362,6 +1388,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             total += cpos;
                             pos = j;
                         }
+#ifdef TAMP_PROF
+                        dbg_hop += __builtin_readcyclecounter() - ht0;
+#endif
                         if (nqueued > 64 - 34) list_queued();  // room for the next chain of hops (at most blk / 64 = 32 blocks)
                         wk.ntok += total;
                         if constexpr (LAZY) {
@@ -1429,6 +1458,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 list_queued();
+#ifdef TAMP_PROF
+                if (a.dbg & 0x2000u) wk.dbg_lag_rle += (uint32_t)dbg_hop, wk.dbg_lag_ext += (uint32_t)dbg_list, wk.dbg_lag_rle_short += (uint32_t)dbg_calls;
+#endif
                 if (act == kActRebase) {
                     // drop the lag, keep the bytes a pending RLE run / extended match has consumed but not
                     // written (oracle/tamp_model.c m_epoch_begin)
@@ -1656,7 +1688,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         }
 #ifdef TAMP_PROF
         if (tid == 0 && a.prof) {
-            if (a.dbg & 0x1000u) pt[6] = wk.dbg_lag_rle, pt[7] = wk.dbg_lag_ext, pt[8] = wk.dbg_lag_rle_short;  // lag causes instead of the fine timers
+            if (a.dbg & 0x3000u) pt[6] = wk.dbg_lag_rle, pt[7] = wk.dbg_lag_ext, pt[8] = wk.dbg_lag_rle_short;  // lag causes instead of the fine timers
             for (int i = 0; i < 16; i++) atomicAdd(&a.prof[i], pt[i]);
         }
 #endif
