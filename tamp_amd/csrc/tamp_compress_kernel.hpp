@@ -327,6 +327,7 @@ struct Walk {
             uint32_t hits = 0;
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
+                if (k * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
                 const uint32_t c = c0 + k * kWave;
                 const bool valid = c + cnt + 1 <= W;
                 const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
