@@ -268,6 +268,9 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
                             : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
     if (conf->window == 10 && packed && !a.lazy && !getenv("TAMP_AMD_NOWSCAN"))  // bucket-scan constants as immediates
         kernel = runlist ? tamp_compress_kernel<true, false, true, 1024> : tamp_compress_kernel<true, false, false, 1024>;
+    // short blocks (one wavefront per stream): 512 buckets -- a quarter of the cursors to zero and scan per message
+    // (256-byte telemetry 39.4 -> 40.2 GB/s; 1,024 buckets the same)
+    if (threads == 64 && packed && !a.lazy && !runlist && !getenv("TAMP_AMD_NOSHORT")) kernel = tamp_compress_kernel<true, false, false, 0, 9>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
     timing_begin(st);

@@ -143,9 +143,10 @@ __device__ __forceinline__ uint32_t tok_nbits(uint32_t i) { return (uint32_t)(kN
 // 16-bit bijective mix of a bigram: top kHashBits select the bucket, the rest ride in the entry.
 __device__ __forceinline__ uint32_t mix16(uint32_t pair16) { return (pair16 * 40503u) & 0xFFFFu; }
 // entry payload from 4 little-endian bytes b0..b3 at a position: rem | b2 | low bits of b3, in bits 16..31
+template <uint32_t REM = kRemBits>
 __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix) {
-    return ((mix & ((1u << kRemBits) - 1)) << 16) | (((bytes4 >> 16) & 0xFFu) << (16 + kRemBits)) |
-           ((bytes4 >> 24) << (24 + kRemBits));
+    return ((mix & ((1u << REM) - 1)) << 16) | (((bytes4 >> 16) & 0xFFu) << (16 + REM)) |
+           ((bytes4 >> 24) << (24 + REM));
 }
 
 // Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  Branch-free: 64 lanes in
@@ -555,8 +556,12 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // inside that loop (v_readlane + s_nop per entry: 4 % of the kernel, the "same code, 4 % slower" builds of section 3.6
 // of DESIGN.md).  Making W a constant for the whole kernel lets the compiler unroll and hoist elsewhere and costs 50+
 // spilled VGPRs, hence the narrow use.
-template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0>
+template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits>
 __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a) {
+    // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
+    // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
+    static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
+    constexpr uint32_t kRem = 16 - HB, kBuckets = 1u << HB;
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t a_wbits = a.wbits, a_blk = a.blk;
@@ -691,7 +696,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         for (uint32_t k = tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
                     }
                 }
-                for (uint32_t k = tid; k < kHashBuckets / 2; k += nt) cntw[k] = 0;
+                for (uint32_t k = tid; k < kBuckets / 2; k += nt) cntw[k] = 0;
                 if (tid == 0) ctl[cCut] = 0xFFFFFFFFu;
                 __syncthreads();
                 TAMP_PROF_MARK(0);
@@ -726,7 +731,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
                         if (c4 + j < NE0) {
-                            const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRemBits;
+                            const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRem;
                             atomicAdd(&cntw[h >> 1], 1u << ((h & 1) * 16));
                         }
                     }
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 {  // exclusive scan of the 2048 u16 counters in place
-                    const uint32_t per = kHashBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
+                    const uint32_t per = kBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
                     uint32_t sum = 0;
                     for (uint32_t k = 0; k < per; k++) sum += cnt16[tid * per + k];
                     uint32_t incl = sum;
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 // its oldest window byte starts (qstart) and after the tile holding its own position (top, in bidx).
                 if (tid < nvalid) {
                     const uint32_t b4 = lds_u32_unaligned(ebuf, W + tid);
-                    qstart[tid] = cnt16[mix16(b4 & 0xFFFFu) >> kRemBits];  // queries of tile 0: bucket start
+                    qstart[tid] = cnt16[mix16(b4 & 0xFFFFu) >> kRem];  // queries of tile 0: bucket start
                 }
                 __syncthreads();
                 for (uint32_t t0 = 0; t0 < NE; t0 += nt) {
@@ -820,14 +825,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     if (c < NE) {
                         const uint32_t b4 = lds_u32_unaligned(ebuf, c);
                         const uint32_t mx = mix16(b4 & 0xFFFFu);
-                        h = mx >> kRemBits;
+                        h = mx >> kRem;
                         const uint32_t sh = (h & 1) * 16;
                         bool keep = true;
                         if constexpr (RUNS) { if (nruns) keep = !((rbits[c >> 5] >> (c & 31u)) & 1u); }
                         if (keep) {
                             const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
                             if (PACKED)
-                                ent[(old >> sh) & 0xFFFFu] = c | entry_payload(b4, mx);
+                                ent[(old >> sh) & 0xFFFFu] = c | entry_payload<kRem>(b4, mx);
                             else
                                 ent16[(old >> sh) & 0xFFFFu] = (uint16_t)c;
                         }
@@ -837,7 +842,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t q2 = t0 + nt + tid;  // queries whose oldest window byte lies in the next tile
                     if (q2 < nvalid) {
                         const uint32_t b4 = lds_u32_unaligned(ebuf, W + q2);
-                        qstart[q2] = cnt16[mix16(b4 & 0xFFFFu) >> kRemBits];
+                        qstart[q2] = cnt16[mix16(b4 & 0xFFFFu) >> kRem];
                     }
                     __syncthreads();
                 }
@@ -919,7 +924,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     if (R >= minp && !in_run) {
 #endif
                         const uint32_t cap_len = R < maxp ? R : maxp;
-                        const uint32_t pk = entry_payload(P[0], mix16(P[0] & 0xFFFFu));
+                        const uint32_t pk = entry_payload<kRem>(P[0], mix16(P[0] & 0xFFFFu));
                         const uint32_t chi = q + W - 2;  // newest candidate served by the index
                         const uint32_t s_hi = bidx[q];
                         uint32_t sl = qstart[q], wrapmask = 0;
@@ -948,10 +953,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                 const uint32_t i = (e + e_wp) & (Ws - 1);  // window index (payload bits masked off)
                                 // in the window and the same bigram.  (Index W-1 cannot start a match: its limit
                                 // W - i = 1 rejects it below.)
-                                if (d <= Ws - 2 && (x & ((1u << kRemBits) - 1)) == 0) {
+                                if (d <= Ws - 2 && (x & ((1u << kRem) - 1)) == 0) {
                                     const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
-                                    uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
-                                    if ((x >> kRemBits) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                                    uint32_t len = (x & (0xFFu << kRem)) ? 2u : 3u;
+                                    if ((x >> kRem) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
                                     // The candidate's first t bytes lie in front of the newest window byte, where the
                                     // buffer IS the ring: a common prefix shorter than t is exact whatever follows.  Only
                                     // a candidate that agrees all the way to the newest byte (periodic input: rare) goes
@@ -987,18 +992,18 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const uint32_t x = PACKED ? (e ^ pk) >> 16 : 0u;
                             const uint32_t i = (e_wp + c) & mask;  // window index of the candidate
                             // in the window, same bigram, and not index W-1 (which cannot start a match)
-                            const bool same = (x & ((1u << kRemBits) - 1)) == 0 && i != mask;
+                            const bool same = (x & ((1u << kRem) - 1)) == 0 && i != mask;
                             const bool ok = c >= q && c <= chi && same;
                             const bool okB = cap_lenB && c >= q && c + 1 <= chi && same;  // window [q-1, q+W-1); c = q-1 apart
                             const uint32_t lim = min(cap_len, W - i);  // may not run past index W-1
                             const uint32_t t = q + W - c;              // bytes before the candidate reaches the newest byte
-                            uint32_t len = (x & (0xFFu << kRemBits)) ? 2u : 3u;
-                            if ((ok || okB) && (x >> kRemBits) == 0 && t > 16) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+                            uint32_t len = (x & (0xFFu << kRem)) ? 2u : 3u;
+                            if ((ok || okB) && (x >> kRem) == 0 && t > 16) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
                             if (ok) {
                                 if (t < 16) {
                                     wrapmask |= 1u << t;  // runs past the newest window byte: resolved after the loop
                                 } else {
-                                    const uint32_t la = t == 16 && (x >> kRemBits) == 0 ? prefix_len16(ebuf, c, P) : len;
+                                    const uint32_t la = t == 16 && (x >> kRem) == 0 ? prefix_len16(ebuf, c, P) : len;
                                     const uint32_t l2 = min(la, lim);
                                     const uint32_t k = (l2 << 16) | (W - i);
                                     if (l2 >= 2 && k > key) key = k;
