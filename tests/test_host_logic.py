@@ -195,3 +195,34 @@ def test_cli_dictionary_rule_and_arguments(tmp_path):
     for bad in (["compress", "-w", "7"], ["compress", "-l", "9"], ["decompress", "--lazy-matching"]):
         with pytest.raises(SystemExit):
             ap.parse_args(bad)
+
+
+def test_compress_kernels_keep_everything_in_registers(tmp_path):
+    """The compress kernels run at the register limit of six workgroups per CU; a spilled VGPR costs a scratch store per
+    lane and stream (round 1: 40 % extra HBM traffic).  Compile the device code with the resource remarks on and require
+    0 spilled VGPRs / 0 B of scratch for every instantiation of tamp_compress_kernel (hipcc cross-compiles without a GPU)."""
+    import os
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tamp_amd", "csrc")
+    p = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-I" + os.path.join(root, "include"),
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "tamp_capi.hip", "-o", str(tmp_path / "dev.o")],
+                       cwd=src, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "tamp_compress_kernel" not in name:
+            continue
+        seen += 1
+        spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+    assert seen >= 6
