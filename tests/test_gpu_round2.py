@@ -512,3 +512,41 @@ def test_long_runs_anywhere_in_the_block_match_oracle(ta, oracle, monkeypatch, w
             gs = _streams_of(r, n)
             for i in range(n):
                 assert gs[i] == want.stream(i), (cut, runs, i)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# split decoder: the streams it hands on (lag list full, output beyond its LDS rows) still come back right
+# --------------------------------------------------------------------------------------------------------------
+def test_split_decoder_leftovers_go_to_the_wave_decoder(ta, oracle, monkeypatch):
+    """One batch mixing ordinary text with (a) streams of a hundred RLE runs longer than 8 bytes -- every one a lag, more
+    than the 48 the parse kernel lists per stream --, (b) a stream that decodes to more than 16,384 bytes, (c) streams
+    whose output capacity cuts a run / an extended match short.  Forced split decoder and the launcher's own choice."""
+    from tamp_amd import workloads as wl
+
+    rng = np.random.default_rng(5)
+    plain = [wl.synth_text(1, 5000, first_index=40 + i)[0].tobytes() for i in range(300)]
+    laggy = []
+    for i in range(6):
+        parts = []
+        for k in range(100):
+            parts.append(bytes([65 + (k + i) % 20]) * int(rng.integers(10, 40)))
+            parts.append(wl.synth_text(1, 64, first_index=1000 + 100 * i + k)[0].tobytes()[: int(rng.integers(3, 30))])
+        laggy.append(b"".join(parts))
+    big = [wl.synth_text(1, 40000, first_index=7)[0].tobytes()]
+    datas = plain[:150] + laggy + big + plain[150:]
+    comps = []
+    for dta in datas:
+        st, comp = oracle.compress(dta)
+        assert st == 0
+        comps.append(comp)
+    for mode in ("split", None):
+        if mode:
+            monkeypatch.setenv("TAMP_AMD_DECODER", mode)
+        else:
+            monkeypatch.delenv("TAMP_AMD_DECODER", raising=False)
+        for cap in (50000, 5000, 4990):
+            res = ta.decompress_batch(comps, out_cap=cap)
+            for i, comp in enumerate(comps):
+                st, want, consumed = oracle.decompress(comp, cap=cap)
+                assert (int(res.status[i]), res.stream(i)) == (st, want), (mode, cap, i)
+                assert int(res.in_consumed[i]) == consumed, (mode, cap, i)
