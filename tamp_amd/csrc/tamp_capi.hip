@@ -52,6 +52,9 @@ struct DeviceCtx {
         uint32_t* scan = nullptr;  // header pre-pass results (largest window / longest stream / window bytes / largest out_cap)
         uint8_t* split = nullptr;  // split decoder: token records, per-stream meta words, lag lists, fallback flags
         size_t split_bytes = 0;
+        // held from the first look at the slab to the last launch of a call: a second host thread using the same stream
+        // could otherwise grow (synchronise, free, allocate) the slab between this call's pointer read and its launch
+        std::mutex launch_mu;
     };
     std::map<hipStream_t, Slab> slabs;
     // host-memory batch calls (TAMP_AMD_MEM_HOST): kept staging buffers and the library's own streams, so that a
@@ -344,6 +347,12 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.scratch = nullptr;
     a.only_flagged = nullptr;
     a.n_streams = (uint32_t)n_streams;
+    DeviceCtx::Slab* call_slab = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        call_slab = &ctx->slabs[st];  // (map nodes do not move)
+    }
+    std::lock_guard<std::mutex> call_lock(call_slab->launch_mu);
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
     uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)
     uint64_t window_bytes = 0;          // sum of the streams' window sizes (0 = unknown)
