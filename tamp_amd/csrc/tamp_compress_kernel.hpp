@@ -590,7 +590,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
     uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
     uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
-    volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(smem + L.ctl);
+    // (an explicit LDS pointer: the address-space inference leaves volatile accesses alone, and through a generic pointer
+    // every control word was a FLAT load with system scope followed by a full wait)
+    typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
+    LdsCtl* const ctl = (LdsCtl*)(smem + L.ctl);
     uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 80);
     // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
     uint8_t* const codetab = smem + L.ctl + 80 + 256;
@@ -725,7 +728,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         if (cut_run && d1 == d0 && c4 >= W + e_pending + 4 && c4 + 4 * cut_run <= NE0) {
                             bool all = true;
                             for (uint32_t k = 2; k < cut_run; k++) all = all && *reinterpret_cast<const uint32_t*>(ebuf + c4 + 4 * k) == d0;
-                            if (all) atomicMin(const_cast<uint32_t*>(&ctl[cCut]), c4);
+                            if (all) atomicMin((uint32_t*)&ctl[cCut], c4);
                         }
                     }
 #pragma unroll
@@ -773,7 +776,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                     while (e < lim && ebuf[e] == x) e++;
                                 }
                                 if (e - c >= kLongRun) {
-                                    const uint32_t slot = atomicAdd(const_cast<uint32_t*>(&ctl[cNruns]), 1u);
+                                    const uint32_t slot = atomicAdd((uint32_t*)&ctl[cNruns], 1u);
                                     if (slot < kRunCap) {
                                         runs[slot] = c | (e << 16);
                                         for (uint32_t k = c + 1; k <= e - 4;) {  // bits [c+1, e-4]
@@ -1560,7 +1563,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 uint32_t v, nb;
                 for (uint32_t k = k0; k < k1; k++)
                     if (!token(k, v, nb)) {
-                        atomicMin(const_cast<uint32_t*>(&ctl[cExcess]), k);
+                        atomicMin((uint32_t*)&ctl[cExcess], k);
                         break;
                     }
                 __syncthreads();
