@@ -447,7 +447,9 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     uint8_t* const outb = smem;                                             // capa bytes (+16)
     uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);    // capa entries: src[p] == p <=> outb[p] is final
     uint32_t* const lagl = reinterpret_cast<uint32_t*>(smem + capa + 16 + 2 * capa);  // kSplitMaxLag x 2
-    volatile uint32_t* const ctl = reinterpret_cast<volatile uint32_t*>(lagl + 2 * kSplitMaxLag);  // 16 words
+    // 16 control words; an explicit LDS pointer (volatile accesses through a generic pointer compile to FLAT loads)
+    typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
+    LdsCtl* const ctl = (LdsCtl*)(lagl + 2 * kSplitMaxLag);
 
     for (uint32_t i = tid; i < 2 * nlag; i += nt) lagl[i] = sa.lag[(size_t)k * kSplitMaxLag * 2 + i];
     __syncthreads();
