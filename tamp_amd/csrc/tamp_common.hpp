@@ -64,6 +64,27 @@ __device__ __forceinline__ uint32_t lds_u32_unaligned(const uint8_t* base, uint3
 #endif
 }
 
+// Inclusive scans over the 64 lanes with DPP row shifts and row broadcasts (six data-parallel-primitive moves instead of
+// six ds_bpermute round trips through the LDS pipe with their lane-index arithmetic: __shfl_up compiles to the latter).
+// row_shr:n keeps `old` (the identity) where the source lane lies outside the 16-lane row; row_bcast:15 / :31 hand the
+// last lane of a row / of the lower half to the rows the row mask selects.
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t identity, Op op) {
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x112, 0xF, 0xF, false));  // row_shr:2
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x114, 0xF, 0xF, false));  // row_shr:4
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x118, 0xF, 0xF, false));  // row_shr:8
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+    return wave_scan_incl(x, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+    return wave_scan_incl(x, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -797,12 +797,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t per = kBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
                     uint32_t sum = 0;
                     for (uint32_t k = 0; k < per; k++) sum += cnt16[tid * per + k];
-                    uint32_t incl = sum;
-#pragma unroll
-                    for (int off = 1; off < kWave; off <<= 1) {
-                        uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                        if (lane >= off) incl += o;
-                    }
+                    const uint32_t incl = wave_scan_add(sum);
                     if (lane == kWave - 1) ctl[cWave + wave] = incl;
                     __syncthreads();
                     uint32_t run = incl - sum;
@@ -861,12 +856,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 __syncthreads();
                 if (wave == 0) {
                     const uint32_t v = bins[lane];
-                    uint32_t incl = v;
-#pragma unroll
-                    for (int off = 1; off < kWave; off <<= 1) {
-                        uint32_t o2 = (uint32_t)__shfl_up((int)incl, off);
-                        if (lane >= off) incl += o2;
-                    }
+                    const uint32_t incl = wave_scan_add(v);
                     bins[lane] = incl - v;
                 }
                 __syncthreads();
@@ -1576,12 +1566,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 token(k, v, nb);
                 mybits += nb;
             }
-            uint32_t incl = mybits;
-#pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                uint32_t o2 = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl += o2;
-            }
+            const uint32_t incl = wave_scan_add(mybits);
             if (lane == kWave - 1) ctl[cWave + wave] = incl;
             __syncthreads();
             uint32_t o = carry + incl - mybits, segbits = 0;

@@ -483,12 +483,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         const uint32_t j0 = min(tid * K, ntok), j1 = min(j0 + K, ntok);
         uint32_t sum = 0;
         for (uint32_t j = j0; j < j1; j++) sum += (rec[j] >> 2) & 0xFFu;
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-            if (lane >= (uint32_t)off) incl += o;
-        }
+        const uint32_t incl = wave_scan_add(sum);
         if (lane == kWave - 1) ctl[wave] = incl;
         __syncthreads();
         uint32_t O = incl - sum;
@@ -516,12 +511,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++)
             if ((h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) last = p0 + i + 1;
-        uint32_t inc = last;  // inclusive max-scan over the wave
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-            if (lane >= (uint32_t)off) inc = max(inc, o);
-        }
+        const uint32_t inc = wave_scan_max(last);  // inclusive max-scan over the wave
         if (lane == kWave - 1) ctl[8 + wave] = inc;
         __syncthreads();
         uint32_t head = (uint32_t)__shfl_up((int)inc, 1);  // last mark in front of this thread's bytes (position + 1)
