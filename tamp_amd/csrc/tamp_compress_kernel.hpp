@@ -601,6 +601,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
 
     const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
+    const uint32_t nt_log2 = nt == 256 ? 8u : 6u;  // (256 or 64 threads: divisions by the block size are shifts)
     uint32_t tid = tid_k;
     int lane = tid & (kWave - 1);
     uint32_t wave = tid >> 6;
@@ -794,7 +795,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 {  // exclusive scan of the 2048 u16 counters in place
-                    const uint32_t per = kBuckets / nt;  // 8 (256 threads) or 32 (64 threads)
+                    const uint32_t per = kBuckets >> nt_log2;  // 8 (256 threads) or 32 (64 threads)
                     uint32_t sum = 0;
                     for (uint32_t k = 0; k < per; k++) sum += cnt16[tid * per + k];
                     const uint32_t incl = wave_scan_add(sum);
@@ -1503,7 +1504,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
             uint32_t act = ctl[cAct];
             const uint32_t ntok = ctl[cNtok];
-            const uint32_t K = (ntok + nt - 1) / nt;
+            const uint32_t K = (ntok + nt - 1) >> nt_log2;
             const uint32_t k0 = min(tid * K, ntok), k1 = min(k0 + K, ntok);
             auto token = [&](uint32_t k, uint32_t& v, uint32_t& nb) -> bool {  // false: literal with excess bits
                 const uint32_t e = toklist[k];

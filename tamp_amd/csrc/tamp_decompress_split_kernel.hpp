@@ -442,7 +442,8 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     const uint8_t* const dict = dict_sel == 3 ? a.dict : a.seed_dicts + ((size_t)dict_sel << 15);
     const uint32_t* const rec = sa.recs + (size_t)k * sa.tokcap;
 
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, nt = blockDim.x;
+    constexpr uint32_t nt = 256;  // (the launcher's block size: a constant keeps divisions by it shifts)
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const uint32_t capa = align_up(sa.maxcap, 16);
     uint8_t* const outb = smem;                                             // capa bytes (+16)
     uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);    // capa entries: src[p] == p <=> outb[p] is final
@@ -514,8 +515,8 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         const uint32_t inc = wave_scan_max(last);  // inclusive max-scan over the wave
         if (lane == kWave - 1) ctl[8 + wave] = inc;
         __syncthreads();
-        uint32_t head = (uint32_t)__shfl_up((int)inc, 1);  // last mark in front of this thread's bytes (position + 1)
-        if (lane == 0) head = 0;
+        // last mark in front of this thread's bytes (position + 1): the scan shifted by one lane (DPP wave_shr:1, 0 into lane 0)
+        uint32_t head = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);
         for (uint32_t w2 = 0; w2 < wave; w2++) head = max(head, (uint32_t)ctl[8 + w2]);
         const uint32_t carry_in = carry;
         head = max(head, carry);
