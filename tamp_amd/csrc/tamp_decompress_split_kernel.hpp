@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         }
         nflushed += 16;
         nstage -= 16;
-        for (uint32_t i = 0; i < nstage; i++) rb[i] = rb[16 + i];
+        st16(reinterpret_cast<uint8_t*>(rb), ld16(reinterpret_cast<const uint8_t*>(rb + 16)));  // (the up to four records behind)
     };
     uint32_t ip = 0, op = 0, ntok = 0, nlag = 0, cumlag = 0;
     uint32_t V = 0;  // bytes written to the window so far (window_pos = V mod W on a fresh decoder)
