@@ -236,6 +236,12 @@ struct Walk {
         if (other_is_window) contig = min(contig, W - rj);
         contig = min(contig, lim);
         uint32_t nn = 0;
+        while (nn + 8 <= contig) {  // eight bytes per LDS round trip (extended matches run to 100+ bytes; sixteen spill a VGPR)
+            const uint32_t x0 = lds_u32_unaligned(ebuf, a + nn) ^ lds_u32_unaligned(ebuf, b + nn);
+            const uint32_t x1 = lds_u32_unaligned(ebuf, a + nn + 4) ^ lds_u32_unaligned(ebuf, b + nn + 4);
+            if (x0 | x1) return nn + (x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : 4 + ((uint32_t)__builtin_ctz(x1) >> 3));
+            nn += 8;
+        }
         while (nn + 4 <= contig) {
             const uint32_t x = lds_u32_unaligned(ebuf, a + nn) ^ lds_u32_unaligned(ebuf, b + nn);
             if (x) return nn + ((uint32_t)__builtin_ctz(x) >> 3);
