@@ -226,3 +226,19 @@ def test_compress_kernels_keep_everything_in_registers(tmp_path):
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         assert spill == 0 and scratch == 0, (name, spill, scratch)
     assert seen >= 6
+    # ... and no FLAT memory instruction in the kernels whose control words live in LDS: a volatile generic pointer makes
+    # every access one (system scope + full wait), which is what the explicit LDS pointers of DESIGN.md 3.9 removed
+    p = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-I" + os.path.join(root, "include"),
+                        "-S", "tamp_capi.hip", "-o", str(tmp_path / "dev.s")], cwd=src, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    asm = (tmp_path / "dev.s").read_text()
+    parts = re.split(r"\n(_ZN[^\n:]*):[^\n]*\n", asm)
+    checked = 0
+    for i in range(1, len(parts) - 1, 2):
+        name, body = parts[i], parts[i + 1]
+        if not any(k in name for k in ("tamp_compress_kernel", "tamp_decode_resolve_kernel", "tamp_decode_parse_kernel")):
+            continue
+        body = body.split(".end_amdhsa_kernel")[0]
+        checked += 1
+        assert "flat_load" not in body and "flat_store" not in body, name
+    assert checked >= 8
