@@ -64,7 +64,8 @@ struct SplitArgs {
 // per lane in LDS: a 64-byte input ring and a stage of 20 records that leaves for HBM 16 records (64 bytes) at a time --
 // sixty-four lanes each storing one dword to a slot of its own cost the memory pipeline a transaction per lane and token
 // (the parse ran at a third of its instruction rate however many waves were resident); odd dword stride per lane
-constexpr uint32_t kParseRing = 64, kParseStage = 20, kParseLane = 64 + 4 * kParseStage + 4;
+// (+ 4 bytes behind the ring that mirror its first dword: a bit window is two aligned dwords from anywhere in the ring)
+constexpr uint32_t kParseRing = 64, kParseStage = 20, kParseLane = 64 + 4 + 4 * kParseStage + 8;  // 156 B: odd dword stride
 __host__ __device__ constexpr uint32_t split_parse_lds(uint32_t threads) { return 128u + threads * kParseLane; }
 
 __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
     uint32_t* const rec = sa.recs + (size_t)(live ? k : 0u) * sa.tokcap;
     uint32_t* const lag = sa.lag + (size_t)(live ? k : 0u) * kSplitMaxLag * 2;
     uint8_t* const inr = smem + 128 + threadIdx.x * kParseLane;
-    uint32_t* const rb = reinterpret_cast<uint32_t*>(inr + kParseRing);  // staged records
+    uint32_t* const rb = reinterpret_cast<uint32_t*>(inr + kParseRing + 4);  // staged records
     uint32_t nflushed = 0, nstage = 0;                                    // records in HBM / in the stage
     auto flush16 = [&]() {  // the stage's first 16 records -> HBM as four 16-byte stores; the rest moves to the front
         if (nflushed + 16 <= sa.tokcap) {
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
             }
         };
 
-        // Two loops alternate.  FAST: straight-line decode from a 64-bit bit window (the token decode of the lane
+        // Two loops alternate.  FAST: straight-line decode from a 32-bit bit window read afresh per token (the token decode of the lane
         // decoders' bulk path, tamp_decompress_kernel.hpp, without its data movement), input through a 64-byte ring per lane
         // that 16-byte global loads refill at points common to the wave.  It declines -- at a token boundary, nothing
         // consumed -- whatever it does not cover: the last ~32 input bytes, FLUSH, a token the output has no room for, an
@@ -188,38 +189,33 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
             const uint32_t sp = T >> 3;
             bool fast = sp + 32 <= n;
             const uint32_t sp0 = sp;  // stream byte x lives at inr[(x - sp0) & 63]
-            auto ring_u32 = [&](uint32_t x) { return *reinterpret_cast<const uint32_t*>(inr + ((x - sp0) & (kParseRing - 1))); };
+            // 25+ bits of the stream from bit position t, MSb first: two aligned dwords of the ring, funnel-shifted
+            auto window = [&](uint32_t t) -> uint32_t {
+                const uint32_t o = ((t >> 3) - sp0) & (kParseRing - 1);
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(inr + (o & ~3u));
+                return __builtin_bswap32(__builtin_amdgcn_alignbyte(w[1], w[0], o & 3u)) << (t & 7);
+            };
             B16 cb = {{0, 0, 0, 0}};
             bool cb_valid = false;
-            uint32_t rp = sp, fill = sp, ld_off = sp, wnext = 0, fn = 0;
-            uint64_t fb = 0;
+            uint32_t fill = sp, ld_off = sp;  // stream bytes [.., fill) are in the ring; next chunk to load
             if (fast) {
-                st16(inr, ld16(in + sp));
+                const B16 c0 = ld16(in + sp);
+                st16(inr, c0);
                 st16(inr + 16, ld16(in + sp + 16));
+                *reinterpret_cast<uint32_t*>(inr + kParseRing) = c0.w[0];
                 fill = ld_off = sp + 32;
-                fb = (uint64_t)__builtin_bswap32(ring_u32(sp)) << (32 + (T & 7));
-                fn = 32 - (T & 7);
-                rp = sp + 4;
-                wnext = ring_u32(rp);
                 budget = 2;
             }
             const uint32_t T_in = T;
             uint32_t T_mark = T;  // bit position at the reference's most recent refill
-            auto refill32 = [&]() -> bool {
-                if (rp + 4 > fill) return false;
-                fb |= (uint64_t)__builtin_bswap32(wnext) << (32 - fn);
-                fn += 32;
-                rp += 4;
-                wnext = ring_u32(rp);  // (may be a stale slot: it is not used before `fill` has passed it)
-                return true;
-            };
             uint32_t step = 0;
             while (__ballot(fast)) {
                 if ((step++ & 3) == 0 && fast) {  // ---- I/O point ----
                     if (nstage >= 16) flush16();
-                    if (cb_valid && fill + 16 - (rp - 4) <= kParseRing) {
-                        st16(inr + ((fill - sp0) & (kParseRing - 1)), cb);
-                        if (fill == rp) wnext = cb.w[0];
+                    if (cb_valid && fill + 16 - (T >> 3) <= kParseRing) {  // (nothing at or behind the read position is overwritten)
+                        const uint32_t ro = (fill - sp0) & (kParseRing - 1);
+                        st16(inr + ro, cb);
+                        if (ro == 0) *reinterpret_cast<uint32_t*>(inr + kParseRing) = cb.w[0];
                         fill += 16;
                         cb_valid = false;
                     }
@@ -229,43 +225,46 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                         cb_valid = true;
                     }
                 }
-                if (!fast) continue;
+                if (fast) {  // (one exit, state committed in one place: the loop-carried values stay where they are)
                 const uint32_t T0 = T;
-                bool ok = fn >= 32 || refill32();
+                uint32_t Tl = T0;  // bit position inside the token
+                bool ok = (T0 >> 3) + 4 <= fill;  // a dry ring (the end of the input, mostly): the exact loop takes over
                 uint32_t used = 0, tok = 0, wl = 0, kind = kRecLit, arg = 0;
                 uint32_t mark = T0;  // the reference refills at the top of every token (decompressor.c:357-365,431-445)
                 const uint32_t wp = V & mask, room = cap - op;
                 if (ok) {
-                    if (fb >> 63) {  // literal, decompressor.c:466-482
-                        arg = (uint32_t)((fb << 1) >> (64 - lbits));
+                    const uint32_t win = window(T0);
+                    if (win >> 31) {  // literal, decompressor.c:466-482
+                        arg = (win << 1) >> (32 - lbits);
                         used = 1 + lbits, tok = 1, wl = 1, kind = kRecLit;
                         ok = room >= 1;
                     } else {
                         uint32_t sym = 0;
                         used = 2;
-                        if ((fb >> 62) & 1) {
-                            const uint32_t e = lut[(uint32_t)(fb >> 55) & 0x7F];
+                        if ((win >> 30) & 1) {
+                            const uint32_t e = lut[(win >> 23) & 0x7F];
                             sym = e & 15, used = 2 + (e >> 4);
                         }
                         if (sym == kSymFlush) {
                             ok = false;
-                        } else if (!extended || sym < kSymRle) {  // plain match, decompressor.c:529-572
+                        } else if (!extended || sym < kSymRle) {  // plain match, decompressor.c:529-572 (9 + 15 bits at most)
                             tok = sym + minp;
-                            arg = (uint32_t)((fb << used) >> (64 - wbits));
+                            arg = (win << used) >> (32 - wbits);
                             used += wbits;
                             wl = tok, kind = kRecCopy;
                             ok = arg + tok <= W && tok <= room;
                         } else {  // RLE / extended match, decompressor.c:114-273
-                            fb <<= used, fn -= used, T += used;
-                            ok = fn >= 32 || refill32();
+                            Tl += used;
+                            ok = (Tl >> 3) + 4 <= fill;
                             if (ok) {
+                                const uint32_t w2 = window(Tl);
                                 const uint32_t trailing = sym == kSymRle ? 4u : 3u;
                                 uint32_t h = 0, u = 1;
-                                if (fb >> 63) {
-                                    const uint32_t e = lut[(uint32_t)(fb >> 56) & 0x7F];
+                                if (w2 >> 31) {
+                                    const uint32_t e = lut[(w2 >> 24) & 0x7F];
                                     h = e & 15, u = 1 + (e >> 4);
                                 }
-                                const uint32_t value = (h << trailing) + (uint32_t)((fb << u) >> (64 - trailing));
+                                const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
                                 u += trailing;
                                 if (sym == kSymRle) {
                                     tok = value + 2;
@@ -274,29 +273,30 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                                     ok = tok <= room;
                                 } else {
                                     tok = value + minp + 12;
-                                    arg = (uint32_t)((fb << u) >> (64 - wbits));
+                                    ok = ((Tl + u) >> 3) + 4 <= fill;  // the offset gets a window of its own (13 + 15 bits would not fit one)
+                                    arg = window(Tl + u) >> (32 - wbits);
                                     // ... and once more in front of the offset if its buffer (25..32 bits after the
                                     // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
                                     const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
-                                    if (nb_top - (T - T0) - u < wbits) mark = T + u;
+                                    if (nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
                                     u += wbits;
                                     wl = min(tok, W - wp);
                                     kind = kRecCopyExt;
-                                    ok = arg + tok <= W && tok <= room;
+                                    ok = ok && arg + tok <= W && tok <= room;
                                 }
                                 used = u;
                             }
                         }
                     }
                 }
-                if (!ok) {  // (bits of a half-read RLE / extended token are simply read again by the exact loop)
-                    T = T0;
-                    fast = false;
-                    continue;
+                if (ok) {
+                    T = Tl + used;
+                    T_mark = mark;
+                    put(kind, tok, arg, wl);
+                } else {
+                    fast = false;  // (nothing consumed: the exact loop reads the token again from T)
                 }
-                fb <<= used, fn -= used, T += used;
-                T_mark = mark;
-                put(kind, tok, arg, wl);
+                }
             }
             if (T != T_in) {  // the reference's buffer at this token boundary: everything its last refill pulled in
                 last_flush = false;
