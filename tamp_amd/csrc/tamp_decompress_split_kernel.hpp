@@ -208,9 +208,8 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
             }
             const uint32_t T_in = T;
             uint32_t T_mark = T;  // bit position at the reference's most recent refill
-            uint32_t step = 0;
             while (__ballot(fast)) {
-                if ((step++ & 3) == 0 && fast) {  // ---- I/O point ----
+                if (fast) {  // ---- I/O point: every fourth step, the same step for the whole wave ----
                     if (nstage >= 16) flush16();
                     if (cb_valid && fill + 16 - (T >> 3) <= kParseRing) {  // (nothing at or behind the read position is overwritten)
                         const uint32_t ro = (fill - sp0) & (kParseRing - 1);
@@ -225,7 +224,9 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                         cb_valid = true;
                     }
                 }
-                if (fast) {  // (one exit, state committed in one place: the loop-carried values stay where they are)
+#pragma unroll 1
+                for (uint32_t quad = 0; quad < 4; quad++)
+                if (fast) {  // (one exit, state committed in one place)
                 const uint32_t T0 = T;
                 uint32_t Tl = T0;  // bit position inside the token
                 bool ok = (T0 >> 3) + 4 <= fill;  // a dry ring (the end of the input, mostly): the exact loop takes over
