@@ -297,10 +297,9 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                         on16 &= 15;
                     }
                 };
-                uint32_t step = 0;
                 enum { kLit = 0, kCopy = 1, kFill = 2 };
                 while (__ballot(fast)) {
-                    if ((step++ & 3) == 0) {  // ---- I/O point ----
+                    {  // ---- I/O point: every fourth step (the inner loop below), the same step for all 64 lanes ----
                         flush_blocks();
                         if (fast) {
                             if (cb_valid && fill + 16 - (rp - 4) <= kLaneInRing) {  // room: the oldest live dword is at rp - 4
@@ -316,6 +315,10 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                             }
                         }
                     }
+                    // (four steps as an inner loop: with the I/O point tested in every step the compiler copied the
+                    // loop-carried state twice per step, a third of the step's vector instructions)
+#pragma unroll 1
+                    for (uint32_t quad = 0; quad < 4; quad++) {
                     if (!fast) continue;
                     if (pend == 0) {  // ---- next token: peek, then commit or leave ----
                         const uint32_t T0 = T;
@@ -409,6 +412,7 @@ __global__ void __launch_bounds__(LDSWIN ? 64 : 256) tamp_decompress_kernel(Deco
                     on16 += olen, op += olen;
                     pend -= olen, p_w -= wlen;
                     if (p_kind == kCopy) p_off += olen;
+                    }
                 }
                 // ---- hand over to the exact loop: staged output out, bit reader rebuilt from the bit position ----
                 flush_blocks();
