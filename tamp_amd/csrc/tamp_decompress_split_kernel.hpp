@@ -103,8 +103,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         nstage -= 16;
         st16(reinterpret_cast<uint8_t*>(rb), ld16(reinterpret_cast<const uint8_t*>(rb + 16)));  // (the up to four records behind)
     };
-    uint32_t ip = 0, op = 0, ntok = 0, nlag = 0, cumlag = 0;
-    uint32_t V = 0;  // bytes written to the window so far (window_pos = V mod W on a fresh decoder)
+    uint32_t ip = 0, op = 0, nlag = 0, cumlag = 0;  // (records so far = nflushed + nstage; bytes written = op - cumlag)
     uint32_t wbits = 8, dict_sel = 2;
     bool fallback = false;
     int res = kInputExhausted;
@@ -134,16 +133,14 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         // one record; `written` = bytes of it that enter the window
         auto put = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written) {
             if (olen == 0) return;
-            if (ntok >= sa.tokcap) fallback = true;
+            if (nflushed + nstage >= sa.tokcap) fallback = true;
             rb[nstage++] = kind | (olen << 2) | (arg << 10);
             if (nstage == kParseStage) flush16();
-            ntok++;
             op += olen;
-            V += written;
             if (written < olen) {  // a lag: later window offsets name bytes further back in the output
                 cumlag += olen - written;
                 if (nlag < kSplitMaxLag) {
-                    lag[2 * nlag] = (op & 0xFFFFu) | ((V & 0xFFFFu) << 16);
+                    lag[2 * nlag] = (op & 0xFFFFu) | (((op - cumlag) & 0xFFFFu) << 16);
                     lag[2 * nlag + 1] = cumlag;
                 } else {
                     fallback = true;
@@ -232,7 +229,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                 bool ok = (T0 >> 3) + 4 <= fill;  // a dry ring (the end of the input, mostly): the exact loop takes over
                 uint32_t used = 0, tok = 0, wl = 0, kind = kRecLit, arg = 0;
                 uint32_t mark = T0;  // the reference refills at the top of every token (decompressor.c:357-365,431-445)
-                const uint32_t wp = V & mask, room = cap - op;
+                const uint32_t wp = (op - cumlag) & mask, room = cap - op;  // (window_pos = bytes written mod W on a fresh decoder)
                 if (ok) {
                     const uint32_t win = window(T0);
                     if (win >> 31) {  // literal, decompressor.c:466-482
@@ -381,7 +378,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                     if (nb == before && ip == n) { starved = true; break; }
                 }
                 if (starved) break;
-                const uint32_t wp = V & mask, room = cap - op;
+                const uint32_t wp = (op - cumlag) & mask, room = cap - op;  // (window_pos = bytes written mod W on a fresh decoder)
                 if (sym == kSymRle) {  // decompressor.c:140-173
                     const uint32_t count = value + 2;
                     const uint32_t w = count <= room ? count : room;
@@ -418,6 +415,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
     if (!live) return;
     for (uint32_t i = 0; i < nstage; i++)
         if (nflushed + i < sa.tokcap) rec[nflushed + i] = rb[i];
+    const uint32_t ntok = nflushed + nstage;
     if (ntok > 0xFFFFFu || op > 0xFFFFu) fallback = true;
     a.out_len[s] = op;
     a.status[s] = (int8_t)res;
