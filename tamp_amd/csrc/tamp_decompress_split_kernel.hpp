@@ -532,17 +532,20 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
             // (a rolled loop over the thread's own LDS entries: unrolled over register copies it was 1,700 VALU
             // instructions of straight-line code for the 16 bytes)
             uint32_t kind = 0, arg = 0, Vj = 0, um = 0;
-            bool have = false;
             const uint32_t pend = min(p0 + 16, n_out);
+            if (head) {  // the token that reaches into this thread's bytes (a mark at p0 replaces it at once)
+                const uint32_t r = rec[jcur];
+                kind = r & 3u, arg = r >> 10;
+                Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
+            }
 #pragma unroll 1
             for (uint32_t p = p0; p < pend; p++) {
                 const uint32_t m = src[p];
-                if (m) jcur = m - 1, hpos = p, have = false;
-                if (!have) {  // (about five times per 16 bytes: the records sit in L1 / L2)
+                if (m) {  // a token starts here (about five times per 16 bytes: the records sit in L1 / L2)
+                    jcur = m - 1, hpos = p;
                     const uint32_t r = rec[jcur];
                     kind = r & 3u, arg = r >> 10;
                     Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
-                    have = true;
                 }
                 uint32_t sp = p, byte = 0;
                 if (kind == kRecLit) {
