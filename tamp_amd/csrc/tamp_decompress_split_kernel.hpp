@@ -227,63 +227,59 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                 const uint32_t T0 = T;
                 uint32_t Tl = T0;  // bit position inside the token
                 bool ok = (T0 >> 3) + 4 <= fill;  // a dry ring (the end of the input, mostly): the exact loop takes over
-                uint32_t used = 0, tok = 0, wl = 0, kind = kRecLit, arg = 0;
                 uint32_t mark = T0;  // the reference refills at the top of every token (decompressor.c:357-365,431-445)
                 const uint32_t wp = (op - cumlag) & mask, room = cap - op;  // (window_pos = bytes written mod W on a fresh decoder)
-                if (ok) {
-                    const uint32_t win = window(T0);
-                    if (win >> 31) {  // literal, decompressor.c:466-482
-                        arg = (win << 1) >> (32 - lbits);
-                        used = 1 + lbits, tok = 1, wl = 1, kind = kRecLit;
-                        ok = room >= 1;
-                    } else {
-                        uint32_t sym = 0;
-                        used = 2;
-                        if ((win >> 30) & 1) {
-                            const uint32_t e = lut[(win >> 23) & 0x7F];
-                            sym = e & 15, used = 2 + (e >> 4);
-                        }
-                        if (sym == kSymFlush) {
-                            ok = false;
-                        } else if (!extended || sym < kSymRle) {  // plain match, decompressor.c:529-572 (9 + 15 bits at most)
-                            tok = sym + minp;
-                            arg = (win << used) >> (32 - wbits);
-                            used += wbits;
-                            wl = tok, kind = kRecCopy;
-                            ok = arg + tok <= W && tok <= room;
-                        } else {  // RLE / extended match, decompressor.c:114-273
-                            Tl += used;
-                            ok = (Tl >> 3) + 4 <= fill;
-                            if (ok) {
-                                const uint32_t w2 = window(Tl);
-                                const uint32_t trailing = sym == kSymRle ? 4u : 3u;
-                                uint32_t h = 0, u = 1;
-                                if (w2 >> 31) {
-                                    const uint32_t e = lut[(w2 >> 24) & 0x7F];
-                                    h = e & 15, u = 1 + (e >> 4);
-                                }
-                                const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
-                                u += trailing;
-                                if (sym == kSymRle) {
-                                    tok = value + 2;
-                                    wl = min(min(tok, kRleWindowMax), W - wp);
-                                    kind = kRecFill, arg = 0;
-                                    ok = tok <= room;
-                                } else {
-                                    tok = value + minp + 12;
-                                    ok = ((Tl + u) >> 3) + 4 <= fill;  // the offset gets a window of its own (13 + 15 bits would not fit one)
-                                    arg = window(Tl + u) >> (32 - wbits);
-                                    // ... and once more in front of the offset if its buffer (25..32 bits after the
-                                    // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
-                                    const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
-                                    if (nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
-                                    u += wbits;
-                                    wl = min(tok, W - wp);
-                                    kind = kRecCopyExt;
-                                    ok = ok && arg + tok <= W && tok <= room;
-                                }
-                                used = u;
+                // literal and plain match decoded side by side and selected (one branch instead of a tree of them: the
+                // values a branch tree assigns on different paths meet in register copies); a stale window of a dry ring
+                // decodes to garbage that `ok` discards
+                const uint32_t win = window(T0);
+                const bool is_lit = (win >> 31) != 0;  // decompressor.c:466-482
+                const uint32_t e0 = lut[(win >> 23) & 0x7F];
+                const bool coded = ((win >> 30) & 1) != 0;
+                const uint32_t sym = coded ? (e0 & 15) : 0u;
+                const uint32_t used_m = coded ? 2 + (e0 >> 4) : 2u;
+                const uint32_t tok_m = sym + minp;  // plain match, decompressor.c:529-572 (9 + 15 bits at most)
+                const uint32_t arg_m = (win << used_m) >> (32 - wbits);
+                uint32_t used = is_lit ? 1 + lbits : used_m + wbits;
+                uint32_t tok = is_lit ? 1u : tok_m;
+                uint32_t wl = tok;
+                uint32_t kind = is_lit ? (uint32_t)kRecLit : (uint32_t)kRecCopy;
+                uint32_t arg = is_lit ? (win << 1) >> (32 - lbits) : arg_m;
+                ok = ok && (is_lit ? room >= 1 : (arg_m + tok_m <= W && tok_m <= room));
+                if (!is_lit && (sym == kSymFlush || (extended && sym >= kSymRle))) {
+                    ok = sym != kSymFlush && (T0 >> 3) + 4 <= fill;
+                    if (ok) {  // RLE / extended match, decompressor.c:114-273
+                        Tl += used_m;
+                        ok = (Tl >> 3) + 4 <= fill;
+                        if (ok) {
+                            const uint32_t w2 = window(Tl);
+                            const uint32_t trailing = sym == kSymRle ? 4u : 3u;
+                            uint32_t h = 0, u = 1;
+                            if (w2 >> 31) {
+                                const uint32_t e = lut[(w2 >> 24) & 0x7F];
+                                h = e & 15, u = 1 + (e >> 4);
                             }
+                            const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
+                            u += trailing;
+                            if (sym == kSymRle) {
+                                tok = value + 2;
+                                wl = min(min(tok, kRleWindowMax), W - wp);
+                                kind = kRecFill, arg = 0;
+                                ok = tok <= room;
+                            } else {
+                                tok = value + minp + 12;
+                                ok = ((Tl + u) >> 3) + 4 <= fill;  // the offset gets a window of its own (13 + 15 bits would not fit one)
+                                arg = window(Tl + u) >> (32 - wbits);
+                                // ... and once more in front of the offset if its buffer (25..32 bits after the
+                                // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
+                                const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
+                                if (nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
+                                u += wbits;
+                                wl = min(tok, W - wp);
+                                kind = kRecCopyExt;
+                                ok = ok && arg + tok <= W && tok <= room;
+                            }
+                            used = u;
                         }
                     }
                 }
