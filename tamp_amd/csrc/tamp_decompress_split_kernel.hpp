@@ -26,6 +26,7 @@
 // tokens or lagging tokens than the scratch slots hold.  Scalar model: the oracle's decoder (oracle/tamp_oracle.c); parity
 // and status / consumed semantics are tested against it for every decoder (tests/test_gpu_parity.py, tools/fuzz_gpu.py).
 #pragma once
+#include <type_traits>
 #include "tamp_common.hpp"
 #include "tamp_decompress_kernel.hpp"
 
@@ -131,11 +132,12 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         if (cap > sa.maxcap) fallback = true;  // (cannot happen: maxcap is the batch maximum)
 
         // one record; `written` = bytes of it that enter the window
-        auto put = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written) {
-            if (olen == 0) return;
+        // (FAST: from the fast loop, where the stage is emptied every four tokens and cannot fill up, and every token has bytes)
+        auto put_any = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written, auto fast_loop) {
+            if (!fast_loop.value && olen == 0) return;
             if (nflushed + nstage >= sa.tokcap) fallback = true;
             rb[nstage++] = kind | (olen << 2) | (arg << 10);
-            if (nstage == kParseStage) flush16();
+            if (!fast_loop.value && nstage == kParseStage) flush16();
             op += olen;
             if (written < olen) {  // a lag: later window offsets name bytes further back in the output
                 cumlag += olen - written;
@@ -147,6 +149,9 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                 }
                 nlag++;
             }
+        };
+        auto put = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written) {
+            put_any(kind, olen, arg, written, std::integral_constant<bool, false>{});
         };
 
         uint32_t bb = 0, nb = 0, stage = 0, ns = 0;
@@ -247,46 +252,37 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                 uint32_t arg = is_lit ? (win << 1) >> (32 - lbits) : arg_m;
                 ok = ok && (is_lit ? room >= 1 : (arg_m + tok_m <= W && tok_m <= room));
                 if (!is_lit && (sym == kSymFlush || (extended && sym >= kSymRle))) {
-                    ok = sym != kSymFlush && (T0 >> 3) + 4 <= fill;
-                    if (ok) {  // RLE / extended match, decompressor.c:114-273
-                        Tl += used_m;
-                        ok = (Tl >> 3) + 4 <= fill;
-                        if (ok) {
-                            const uint32_t w2 = window(Tl);
-                            const uint32_t trailing = sym == kSymRle ? 4u : 3u;
-                            uint32_t h = 0, u = 1;
-                            if (w2 >> 31) {
-                                const uint32_t e = lut[(w2 >> 24) & 0x7F];
-                                h = e & 15, u = 1 + (e >> 4);
-                            }
-                            const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
-                            u += trailing;
-                            if (sym == kSymRle) {
-                                tok = value + 2;
-                                wl = min(min(tok, kRleWindowMax), W - wp);
-                                kind = kRecFill, arg = 0;
-                                ok = tok <= room;
-                            } else {
-                                tok = value + minp + 12;
-                                ok = ((Tl + u) >> 3) + 4 <= fill;  // the offset gets a window of its own (13 + 15 bits would not fit one)
-                                arg = window(Tl + u) >> (32 - wbits);
-                                // ... and once more in front of the offset if its buffer (25..32 bits after the
-                                // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
-                                const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
-                                if (nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
-                                u += wbits;
-                                wl = min(tok, W - wp);
-                                kind = kRecCopyExt;
-                                ok = ok && arg + tok <= W && tok <= room;
-                            }
-                            used = u;
-                        }
-                    }
+                    // RLE / extended match, decompressor.c:114-273 (FLUSH: left to the exact loop).  Straight-line as well:
+                    // windows read from a dry ring are garbage that `ok` discards.
+                    Tl += used_m;
+                    const bool have2 = sym != kSymFlush && (Tl >> 3) + 4 <= fill;
+                    const uint32_t w2 = window(Tl);
+                    const uint32_t trailing = sym == kSymRle ? 4u : 3u;
+                    const bool coded2 = (w2 >> 31) != 0;
+                    const uint32_t e2 = lut[(w2 >> 24) & 0x7F];
+                    const uint32_t h = coded2 ? (e2 & 15) : 0u;
+                    uint32_t u = coded2 ? 1 + (e2 >> 4) : 1u;
+                    const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
+                    u += trailing;
+                    const bool is_rle = sym == kSymRle;
+                    // the offset of an extended match gets a window of its own (13 + 15 bits would not fit one)
+                    const bool have3 = ((Tl + u) >> 3) + 4 <= fill;
+                    const uint32_t arg_x = window(Tl + u) >> (32 - wbits);
+                    // ... and the reference refills once more in front of the offset if its buffer (25..32 bits after the
+                    // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
+                    const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
+                    if (!is_rle && nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
+                    tok = is_rle ? value + 2 : value + minp + 12;
+                    wl = is_rle ? min(min(tok, kRleWindowMax), W - wp) : min(tok, W - wp);
+                    kind = is_rle ? (uint32_t)kRecFill : (uint32_t)kRecCopyExt;
+                    arg = is_rle ? 0u : arg_x;
+                    used = is_rle ? u : u + wbits;
+                    ok = have2 && tok <= room && (is_rle || (have3 && arg_x + tok <= W));
                 }
                 if (ok) {
                     T = Tl + used;
                     T_mark = mark;
-                    put(kind, tok, arg, wl);
+                    put_any(kind, tok, arg, wl, std::integral_constant<bool, true>{});
                 } else {
                     fast = false;  // (nothing consumed: the exact loop reads the token again from T)
                 }
