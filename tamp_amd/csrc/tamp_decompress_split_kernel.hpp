@@ -539,19 +539,16 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
                     kind = r & 3u, arg = r >> 10;
                     Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
                 }
-                uint32_t sp = p, byte = 0;
-                if (kind == kRecLit) {
-                    byte = arg;
-                } else {
-                    const uint32_t idx = kind == kRecFill ? ((Vj - 1) & mask) : arg + (p - hpos);  // ring index read
-                    const uint32_t back = (Vj - 1 - idx) & mask;  // 0 = newest ... W-1 = oldest
-                    if (back >= Vj) {
-                        byte = dict[idx];  // never written: the dictionary
-                    } else {
-                        const uint32_t v = Vj - 1 - back;
-                        sp = nlag ? out_of_virtual(v) : v;
-                    }
-                }
+                // (selects instead of a branch per token kind: the kinds alternate from byte to byte and lane to lane)
+                const bool lit = kind == kRecLit;
+                const uint32_t idx = kind == kRecFill ? ((Vj - 1) & mask) : arg + (p - hpos);  // ring index read
+                const uint32_t back = (Vj - 1 - idx) & mask;  // 0 = newest ... W-1 = oldest
+                const bool from_dict = !lit && back >= Vj;    // never written: the dictionary
+                uint32_t v = Vj - 1 - back;
+                if (nlag && !lit && !from_dict) v = out_of_virtual(v);
+                const uint32_t sp = (lit || from_dict) ? p : v;
+                uint32_t byte = lit ? arg : 0u;
+                if (from_dict) byte = dict[idx];
                 src[p] = (uint16_t)sp;
                 outb[p] = (uint8_t)byte;
                 um |= (sp != p ? 1u : 0u) << (p - p0);
