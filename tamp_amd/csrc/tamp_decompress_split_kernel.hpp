@@ -490,7 +490,6 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
 #if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 1
     return;
 #endif
-    uint32_t um0 = 0, um1 = 0, um2 = 0, um3 = 0;  // this thread's bytes that still point elsewhere, one mask per round
     for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += 16 * nt) {  // 4,096 bytes per round
         const uint32_t p0 = r0 + 16 * tid;
         uint32_t h[8];  // this thread's 16 marks
@@ -523,7 +522,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         if (p0 < n_out) {
             // (a rolled loop over the thread's own LDS entries: unrolled over register copies it was 1,700 VALU
             // instructions of straight-line code for the 16 bytes)
-            uint32_t kind = 0, arg = 0, Vj = 0, um = 0;
+            uint32_t kind = 0, arg = 0, Vj = 0;
             const uint32_t pend = min(p0 + 16, n_out);
             if (head) {  // the token that reaches into this thread's bytes (a mark at p0 replaces it at once)
                 const uint32_t r = rec[jcur];
@@ -551,14 +550,9 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
                 if (from_dict) byte = dict[idx];
                 src[p] = (uint16_t)sp;
                 outb[p] = (uint8_t)byte;
-                um |= (sp != p ? 1u : 0u) << (p - p0);
             }
             // (the thread that owns the last byte of a full round also sees the token that reaches its end)
             if (tid == nt - 1) ctl[12] = jcur;  // the token that reaches the end of this round
-            if (r0 == 0) um0 = um;
-            else if (r0 == 16 * nt) um1 = um;
-            else if (r0 == 32 * nt) um2 = um;
-            else um3 = um;
         }
         __syncthreads();
     }
@@ -567,17 +561,35 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     return;
 #endif
     // ---- pointer jumping: every round halves the chains; a byte is final when it points at itself.  Each thread keeps
-    // working on its own bytes (the masks of the byte pass), so a round costs what is still unresolved. ----
+    // working on its own unresolved bytes (one mask per 4,096 bytes), so a round costs what is still unresolved.  The bytes
+    // of a thread are spread out (byte t, t + 256, t + 512, ... of each 4,096): sixteen neighbours are all literals or all
+    // copies, and lanes in lock step wait for the lane with the most work -- spread out, the counts are nearly equal. ----
     static_assert(kSplitMaxOut <= 4 * 16 * 256, "four masks per thread");
+    uint32_t um0 = 0, um1 = 0, um2 = 0, um3 = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t um = 0;
+        if (q * 16 * nt < n_out) {
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t p = q * 16 * nt + i * nt + tid;
+                um |= ((p < n_out && src[p] != p) ? 1u : 0u) << i;
+            }
+        }
+        if (q == 0) um0 = um;
+        else if (q == 1) um1 = um;
+        else if (q == 2) um2 = um;
+        else um3 = um;
+    }
     for (uint32_t round = 0; round < 17; round++) {
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
             uint32_t um = q == 0 ? um0 : (q == 1 ? um1 : (q == 2 ? um2 : um3));
-            const uint32_t p0 = (q * nt + tid) * 16;
+            const uint32_t p0 = q * 16 * nt + tid;
             for (uint32_t m = um; m;) {
                 const uint32_t i = (uint32_t)__builtin_ctz(m);
                 m &= m - 1;
-                const uint32_t p = p0 + i;
+                const uint32_t p = p0 + i * nt;
                 const uint32_t s1 = src[p];
                 const uint32_t s2 = src[s1];
                 // (program order matters twice: the byte is read after its "final" mark was seen, and written before
