@@ -110,8 +110,40 @@ def gather_files(patterns, max_bytes: int) -> bytes:
     return bytes(buf)
 
 
-def real_text(name: str, max_bytes: int = 64 << 20) -> bytes:
-    """One of REAL_TEXT_SOURCES as a byte string (possibly empty when nothing matches on this machine)."""
+#: frozen real-text corpora (tests/golden/make_corpus.py): 3 MiB each, xz-compressed in the tree
+FROZEN_CORPORA = {"prose": "corpus_prose.txt.xz", "python": "corpus_python.txt.xz"}
+_corpus_cache = {}
+
+
+def frozen_corpus(name: str) -> bytes:
+    """The committed fixture for ``name`` (raw bytes; checked against the manifest's SHA-256), or b"" if absent."""
+    if name in _corpus_cache:
+        return _corpus_cache[name]
+    import hashlib
+    import json
+    import lzma
+
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    path = os.path.join(gold, FROZEN_CORPORA.get(name, ""))
+    raw = b""
+    if os.path.isfile(path):
+        raw = lzma.decompress(open(path, "rb").read())
+        with open(os.path.join(gold, "corpus_manifest.json")) as fh:
+            want = json.load(fh)[name]
+        if hashlib.sha256(raw).hexdigest() != want["sha256"] or len(raw) != want["raw_bytes"]:
+            raise RuntimeError(f"frozen corpus {name!r} does not match its manifest")
+    _corpus_cache[name] = raw
+    return raw
+
+
+def real_text(name: str, max_bytes: int = 64 << 20, frozen_only: bool = False) -> bytes:
+    """Real text for throughput / parity runs: the frozen fixture first (so numbers do not move with the machine or with
+    this repo's own markdown), topped up from REAL_TEXT_SOURCES only when more than the fixture holds is asked for."""
+    raw = frozen_corpus(name)
+    if len(raw) >= max_bytes or frozen_only:
+        return raw[:max_bytes]
+    if raw:
+        return raw  # the fixture is the corpus; callers tile it when they need more streams
     return gather_files(REAL_TEXT_SOURCES[name], max_bytes)
 
 

@@ -47,8 +47,7 @@ def test_real_text_4k_chunks_match_reference(ta, checker, corpus):
     from tamp_amd import workloads as wl
 
     blob = wl.real_text(corpus, 6 << 20)
-    if len(blob) < 64 * 4096:
-        pytest.skip(f"no {corpus} corpus on this machine")
+    assert len(blob) >= 3 << 20, "the frozen corpus (tests/golden/corpus_*.txt.xz) is part of the tree"
     # every stream of the first 2 MiB, then every fifth chunk of the rest: ~750 streams, the short tail included
     head, rest = blob[: (2 << 20) + 777], blob[(2 << 20) + 777 :]
     flat, off, ln = wl.split_fixed(head, 4096, keep_tail=True)
@@ -81,8 +80,7 @@ def test_real_text_one_long_stream_and_other_windows(ta, checker):
     from tamp_amd import workloads as wl
 
     blob = wl.real_text("prose", 1 << 20)
-    if len(blob) < 300_000:
-        pytest.skip("no prose corpus on this machine")
+    assert len(blob) >= 300_000, "the frozen corpus (tests/golden/corpus_prose.txt.xz) is part of the tree"
     for size in (65536, 300_000):
         data = np.frombuffer(blob[:size], dtype=np.uint8)
         off, ln = np.zeros(1, np.uint64), np.array([size], np.uint32)
@@ -109,8 +107,7 @@ def test_corpus_hook_of_bench(ta, tmp_path):
     from tamp_amd import workloads as wl
 
     blob = wl.real_text("prose", 3 << 20)
-    if len(blob) < (1 << 20):
-        pytest.skip("no prose corpus on this machine")
+    assert len(blob) >= (1 << 20), "the frozen corpus (tests/golden/corpus_prose.txt.xz) is part of the tree"
     p = tmp_path / "corpus.txt"
     p.write_bytes(blob[: (1 << 20) + 123])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--corpus", str(p), "--steps", "2", "--warmup", "1"],

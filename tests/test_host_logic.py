@@ -242,3 +242,15 @@ def test_compress_kernels_keep_everything_in_registers(tmp_path):
         checked += 1
         assert "flat_load" not in body and "flat_store" not in body, name
     assert checked >= 8
+
+
+def test_frozen_corpora_match_their_manifest():
+    """tests/golden/corpus_{prose,python}.txt.xz: the real-text inputs of the GPU parity tests and of bench.py's
+    `real_text` figures are committed data, not whatever the machine happens to hold."""
+    from tamp_amd import workloads as wl
+
+    for name in ("prose", "python"):
+        raw = wl.frozen_corpus(name)  # raises when the SHA-256 of the manifest does not match
+        assert len(raw) == 3 << 20
+        assert wl.real_text(name, 1 << 20) == raw[: 1 << 20]
+        assert wl.real_text(name, 64 << 20) == raw  # never topped up from the machine

@@ -21,6 +21,8 @@ if WL.startswith('glob:'):
     k = len(blob) // 4096
     rows = np.frombuffer(bytes(blob[:k*4096]), dtype=np.uint8).reshape(k, 4096)
     rows = np.tile(rows, ((n + k - 1) // k, 1))[:n].copy()
+elif WL.startswith('corpus:'):
+    rows = wl.tile_rows(wl.real_text(WL[7:]), n, 4096)
 else:
     rows = getattr(wl, WL)(n, int(os.environ.get('SLEN', '4096')))
 SLEN = rows.shape[1]

@@ -35,10 +35,10 @@ def run(name, rows, **kw):
         cpu = f" | reference C 32 thr: {kk*L/rr.seconds/1e9:5.2f} GB/s"
     print(f"{name:34s} n={n} {min(ms):7.2f} ms {n*L/min(ms)/1e6:6.2f} GB/s ratio={olen.sum()/rows.size:.3f} parity={ok}{cpu}", flush=True)
 N = 16384
-py = corpus(['/usr/lib/python3.10/*.py', '/usr/lib/python3.10/*/*.py'], N*4096)
-md = corpus(['/opt/skills/guides/*.md', os.path.join(os.environ.get('GRAFT_REPO_ROOT','/root/repo'), '*.md'), '/usr/share/common-licenses/*', '/usr/share/doc/*/copyright'], N*4096)
+py = wl.real_text('python')   # frozen fixtures (tests/golden/make_corpus.py)
+md = wl.real_text('prose')
 print(len(py), len(md))
-for name, blob in (("python sources", py), ("markdown/licences (prose)", md)):
+for name, blob in (("python sources (frozen)", py), ("prose (frozen)", md)):
     n = len(blob)//4096
     if n == 0: continue
     rows = np.frombuffer(blob[:n*4096], dtype=np.uint8).reshape(n, 4096).copy()
