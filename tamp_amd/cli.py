@@ -18,33 +18,35 @@ from typing import Optional
 
 
 def load_dictionary(path, window: int, literal: int, extended: bool) -> bytearray:
-    """tamp/cli/main.py:90-105."""
+    """The reference CLI's dictionary rule (tamp/cli/main.py:90-105): a file of exactly the window size IS the window; a
+    shorter one is placed at the END of a seeded window (v1 streams seed with the literal-8 alphabet); a longer one is
+    refused."""
     import tamp_amd
 
-    raw = Path(path).read_bytes()
-    window_size = 1 << window
-    if len(raw) == window_size:
-        return bytearray(raw)
-    if len(raw) > window_size:
-        raise ValueError(f"Dictionary file ({len(raw)} bytes) is larger than window size ({window_size} bytes).")
-    dictionary = tamp_amd.initialize_dictionary(window_size, literal=literal if extended else 8)
-    if raw:
-        dictionary[-len(raw):] = raw
-    return dictionary
+    payload = Path(path).read_bytes()
+    capacity = 1 << window
+    if len(payload) > capacity:
+        raise ValueError(f"Dictionary file ({len(payload)} bytes) is larger than window size ({capacity} bytes).")
+    if len(payload) == capacity:
+        return bytearray(payload)
+    seeded = tamp_amd.initialize_dictionary(capacity, literal=literal if extended else 8)
+    seeded[capacity - len(payload):] = payload
+    return seeded
 
 
-def _read(path: Optional[str]) -> bytes:
-    data = sys.stdin.buffer.read() if path is None else Path(path).read_bytes()
-    if not data:
+def _slurp(path: Optional[str]) -> bytes:
+    """Whole input from a file, or from stdin when no path was given; empty input is an error like in the reference."""
+    blob = Path(path).read_bytes() if path is not None else sys.stdin.buffer.read()
+    if len(blob) == 0:
         raise ValueError("No data provided.")
-    return data
+    return blob
 
 
-def _write(path: Optional[str], data: bytes) -> None:
-    if path is None:
-        sys.stdout.buffer.write(data)
-    else:
-        Path(path).write_bytes(data)
+def _deliver(path: Optional[str], blob: bytes) -> None:
+    if path is not None:
+        Path(path).write_bytes(blob)
+        return
+    sys.stdout.buffer.write(blob)
 
 
 def _bits(lo: int, hi: int):
@@ -82,7 +84,7 @@ def main(argv=None) -> int:
     src = args.input if args.input is not None else args.input_pos
     dst = args.output if args.output is not None else args.output_pos
     try:
-        data = _read(src)
+        data = _slurp(src)
         kwargs = {}
         if args.dictionary is not None:
             kwargs["dictionary"] = load_dictionary(args.dictionary, args.window, args.literal, args.extended)
@@ -94,7 +96,7 @@ def main(argv=None) -> int:
     except (ValueError, IndexError, tamp_amd.ExcessBitsError) as e:
         print(f"tamp_amd: {type(e).__name__}: {e}", file=sys.stderr)
         return 1
-    _write(dst, bytes(out))
+    _deliver(dst, bytes(out))
     return 0
 
 

@@ -14,20 +14,27 @@ _DEFAULT_SEED = 3758097560  # tamp/__init__.py:37, common.c:38
 
 
 def bit_size(value: int) -> int:
-    """Number of bits needed to represent ``value`` (tamp/__init__.py:18-23); -1 if it exceeds 32 bits."""
-    for i in range(32):
-        if not value:
-            return i
-        value >>= 1
-    return -1
+    """Bits needed to hold ``value``; -1 from 2**31 upwards (the contract of tamp/__init__.py:18-23, whose probe stops
+    after 31 shifts)."""
+    width = int(value).bit_length()
+    return width if width < 32 else -1
 
 
-def _xorshift32(seed: int):
+_SEED_ALPHABETS = {  # common.c:18-25: sixteen seed characters per literal width; wider literals get the mark-up set
+    5: bytes(c & 0x1F for c in b" etaoinshrdlcumw"),
+    6: bytes(c & 0x3F for c in b" etaoinshrdlcumw"),
+}
+_SEED_ALPHABET_WIDE = b" \x000ei>to<ans\nr/."
+
+
+def _seed_stream(state: int):
+    """Marsaglia xorshift32 (13, 17, 5) -- the generator behind the seeded dictionary (common.c:27-35)."""
+    m = 0xFFFFFFFF
     while True:
-        seed ^= (seed << 13) & 0xFFFFFFFF
-        seed ^= (seed >> 17) & 0xFFFFFFFF
-        seed ^= (seed << 5) & 0xFFFFFFFF
-        yield seed
+        state = (state ^ (state << 13)) & m
+        state ^= state >> 17
+        state = (state ^ (state << 5)) & m
+        yield state
 
 
 def initialize_dictionary(source, seed=None, literal: int = 8) -> bytearray:
@@ -45,25 +52,17 @@ def initialize_dictionary(source, seed=None, literal: int = 8) -> bytearray:
             n8 = size & ~7  # the reference's Python generator emits whole 8-byte groups only
             lib.tamp_initialize_dictionary(buf, n8, literal)
         return out
-    if literal <= 5:
-        chars = bytes(c & 0x1F for c in b" etaoinshrdlcumw")
-    elif literal <= 6:
-        chars = bytes(c & 0x3F for c in b" etaoinshrdlcumw")
-    else:
-        chars = b" \x000ei>to<ans\nr/."
-    gen = _xorshift32(seed)
-    i = 0
-    for _ in range(size >> 3):
-        value = next(gen)
-        for _ in range(8):
-            out[i] = chars[value & 0x0F]
-            value >>= 4
-            i += 1
+    alphabet = _SEED_ALPHABETS.get(literal, _SEED_ALPHABET_WIDE)
+    draws = _seed_stream(seed)
+    for group in range(size // 8):  # one 32-bit draw seeds eight bytes, low nibble first
+        word = next(draws)
+        out[8 * group : 8 * group + 8] = bytes(alphabet[(word >> (4 * k)) & 15] for k in range(8))
     return out
 
 
 def compute_min_pattern_size(window: int, literal: int) -> int:
-    """tamp/__init__.py:66-70 / common.c:54-56."""
-    if not (7 < window < 16 and 4 < literal < 9):
+    """Shortest match worth a token: 3 once the window outgrows ``10 + 2 * (literal - 5)`` bits, else 2 (common.c:54-56);
+    ``ValueError`` outside window 8..15 / literal 5..8, as the reference's Python twin raises."""
+    if window not in range(8, 16) or literal not in range(5, 9):
         raise ValueError
-    return 2 + (window > (10 + ((literal - 5) << 1)))
+    return 3 if window > 10 + 2 * (literal - 5) else 2

@@ -254,3 +254,28 @@ def test_frozen_corpora_match_their_manifest():
         assert len(raw) == 3 << 20
         assert wl.real_text(name, 1 << 20) == raw[: 1 << 20]
         assert wl.real_text(name, 64 << 20) == raw  # never topped up from the machine
+
+
+def test_helpers_against_values_recorded_from_the_reference():
+    """tests/golden/helpers.json (make_helpers_golden.py): bit_size, compute_min_pattern_size and initialize_dictionary
+    with non-default seeds, as the reference's own Python definitions answer (tamp/__init__.py:18-70)."""
+    import hashlib
+
+    gold = load_golden("helpers.json")
+    for v, want in gold["bit_size"].items():
+        assert tamp_amd.bit_size(int(v)) == want, v
+    for key, want in gold["min_pattern"].items():
+        w, l = map(int, key.split(","))
+        assert tamp_amd.compute_min_pattern_size(w, l) == want
+    for case in gold["seeded"]:
+        got = bytes(tamp_amd.initialize_dictionary(case["size"], seed=case["seed"], literal=case["literal"]))
+        assert got[:16].hex() == case["head"] and hashlib.sha256(got).hexdigest() == case["sha256"], case
+
+
+def test_import_tamp_resolves_to_this_package():
+    """The drop-in name: ``import tamp`` gives the reference's public names, each the very object tamp_amd exports."""
+    import tamp
+
+    for name in ("compress", "decompress", "Compressor", "Decompressor", "TextCompressor", "TextDecompressor", "open",
+                 "initialize_dictionary", "compute_min_pattern_size", "bit_size", "ExcessBitsError"):
+        assert getattr(tamp, name) is getattr(tamp_amd, name), name
