@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtamp_amd.so")
+LIB_PATH = os.environ.get("TAMP_AMD_LIB") or os.path.join(_HERE, "libtamp_amd.so")  # (override: instrumented dev builds)
 
 OK, OUTPUT_FULL, INPUT_EXHAUSTED = 0, 1, 2
 ERROR, EXCESS_BITS, INVALID_CONF, OOB = -1, -2, -3, -4

@@ -23,6 +23,7 @@
 #include "tamp_amd.h"
 #include "tamp_compat.h"
 #include "tamp_compress_kernel.hpp"
+#include "tamp_compress_tile_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_split_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
@@ -266,6 +267,31 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     const uint32_t threads = a.blk >= 1024 ? 256 : 64;
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
+    {
+        // Tile-ring build (tamp_compress_tile_kernel.hpp): windows up to 2^10, default parse, streams long enough for a
+        // 256-thread workgroup.  TAMP_AMD_ENCODER=epoch|tile forces one (tuning / tests).
+        // Opt-in (TAMP_AMD_ENCODER=tile): bit-exact, but measured slower than the epoch kernel on every corpus of round 3
+        // (profiles/ab/README.md: 72 k against 53.6 k VALU instructions per 4 KiB stream, eight latency-bound builds).
+        bool tile = false;
+        if (const char* e = getenv("TAMP_AMD_ENCODER")) {
+            if (!strcmp(e, "tile")) tile = conf->window <= 10 && !a.lazy;
+        }
+        if (tile) {
+            const TileLds TL;
+            auto tk = conf->window == 10 ? tamp_compress_tile_kernel<10>
+                      : conf->window == 9 ? tamp_compress_tile_kernel<9> : tamp_compress_tile_kernel<8>;
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL.total));
+            timing_begin(st);
+            for (size_t first = 0; first < n_streams; first += grid) {
+                a.first_stream = (uint32_t)first;
+                const uint32_t g = (uint32_t)std::min<size_t>(grid, n_streams - first);
+                hipLaunchKernelGGL(tk, dim3(g), dim3(256), TL.total, st, a);
+            }
+            timing_end(st);
+            HIP_OK(hipGetLastError());
+            return TAMP_OK;
+        }
+    }
     auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true> : tamp_compress_kernel<false, true>)
                   : runlist ? (packed ? tamp_compress_kernel<true, false, true> : tamp_compress_kernel<false, false, true>)
                             : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
@@ -978,7 +1004,7 @@ const char* tamp_amd_version(void) { return "tamp_amd 0.1 (gfx950)"; }
 
 const char* tamp_amd_last_error(void) { return t_last_error; }
 
-#ifdef TAMP_PROF
+#if defined(TAMP_PROF) || defined(TAMP_TILE_DBG)
 // debug-only: per-phase cycle counters (not part of the public header)
 int tamp_amd_prof_read(unsigned long long* out6) {
     if (!g_prof) {

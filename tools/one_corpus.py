@@ -9,20 +9,10 @@ dev = torch.device('cuda:0')
 root = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 which = os.environ.get('CORPUS', 'prose')
-pats = {'prose': ['/opt/skills/guides/*.md', os.path.join(root, '*.md'), '/usr/share/common-licenses/*', '/usr/share/doc/*/copyright'],
-        'python': ['/usr/lib/python3.10/*.py', '/usr/lib/python3.10/*/*.py']}
 if which == 'synth':
     rows = wl.synth_text(N, 4096)
 else:
-    buf = bytearray()
-    for pat in pats[which]:
-        for f in sorted(glob.glob(pat)):
-            try: buf += open(f, 'rb').read()
-            except Exception: pass
-            if len(buf) >= N * 4096: break
-    n = len(buf) // 4096
-    rows = np.frombuffer(bytes(buf[:n * 4096]), dtype=np.uint8).reshape(n, 4096)
-    rows = np.tile(rows, ((N + n - 1) // n, 1))[:N]
+    rows = wl.tile_rows(wl.real_text(which), N, 4096)  # frozen fixtures (tests/golden/make_corpus.py)
 off, ln = wl.csr_for_fixed(N, 4096)
 data = torch.from_numpy(rows.reshape(-1).copy()).to(dev); off_t = torch.from_numpy(off.astype(np.int64)).to(dev); len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
 ra = {'0': False, '1': True}.get(os.environ.get('RUNS', ''), None)
