@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r2"     # profiles/<tag>_pmc_{fetch,write}_counter_collection.csv feed roofline.traffic
+PROFILE_TAG = "r3"     # profiles/<tag>_pmc_{fetch,write,sq,sq2}_counter_collection.csv feed roofline.traffic / valu_*
 
 
 class Shard:
@@ -50,21 +50,30 @@ class Shard:
         self.kw = dict(conf_kw, max_in_len=self.max_len, out_cap=self.cap)
         self.torch = torch
         self.events = []
+        self.last = None       # the previous step's result: its slab and tables are the next step's workspace
+        self.host_s = 0.0      # host time spent inside launch() (enqueue cost of this shard), timed region only
+        self.launches = 0
 
     def launch(self, record=False, **over):
         """Enqueue one batch compress on this shard's stream (asynchronous); optionally bracket it with HIP events."""
         import tamp_amd
 
         torch = self.torch
+        t0 = time.perf_counter()
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
             res = tamp_amd.compress_batch(self.data, self.off, self.len, stream=self.stream.cuda_stream,
-                                          **dict(self.kw, **over))
+                                          reuse=None if over else self.last, **dict(self.kw, **over))
             if record:
                 e1.record(self.stream)
                 self.events.append((e0, e1))
+        if not over:
+            self.last = res
+        if record:
+            self.host_s += time.perf_counter() - t0
+            self.launches += 1
         return res
 
     def sync(self):
@@ -236,6 +245,10 @@ def main():
                            + (" [TAMP_BENCH_ONE_DEVICE: all shards on cuda:0]" if one_device else ""),
             "compressed_ratio": round(job_out / max(job_in, 1), 4),
             "all_streams_ok": bool(job_ok),
+            # host time inside the launch call per shard and step (enqueue only: the launches are asynchronous); with one
+            # process driving N devices the sum over shards must stay well under one kernel time or devices starve
+            "host_launch_us_per_shard": round(1e6 * sum(sh.host_s for sh in shards) / max(1, sum(sh.launches for sh in shards)), 1),
+            "sum_kernel_ms_per_step": round(float(sum(np.mean([a.elapsed_time(b) for (a, b) in sh.events]) for sh in shards if sh.events)), 4),
         },
         "roofline": {
             "bound": "hbm",
@@ -256,6 +269,8 @@ def main():
     if corpus_blob is None and args.streams == 65536 and args.stream_len == 4096:
         result["roofline"]["traffic"] = traffic
         result["roofline"]["traffic_source"] = src
+        # the real limiter (SURVEY.md 8d's secondary counters): the kernel is bound by VALU issue, not by HBM
+        result["roofline"].update(pmc_issue_figures(args.streams, sh0.in_bytes))
 
     extras = rank == 0 and not args.no_cpu_baseline
     if extras and world == 1:
@@ -275,6 +290,10 @@ def main():
             also["error"] = repr(e)[:200]
         try:
             also["real_text"] = also_real_text(args, torch, np)
+            # the metric's corpus class next to the synthetic headline (input MB/s, extended format = library default)
+            result["config"]["real_text_MBps"] = {
+                name: round(1000 * v["extended_GBps"]) for name, v in also["real_text"].items()
+                if isinstance(v, dict) and "extended_GBps" in v}
         except Exception as e:
             also["real_text"] = {"error": repr(e)[:200]}
         try:
@@ -310,6 +329,39 @@ def pmc_traffic_bytes():
             "passes, tools/pmc_run.sh) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) + "
             "WRITE_SIZE KB" + ("" if tag == PROFILE_TAG else " [STALE: captured on an earlier build of the kernel]"))
     return None, "no committed PMC pass"
+
+
+def pmc_issue_figures(n_streams, in_bytes):
+    """VALU wave-instructions per stream, VALU busy and the issue ceiling from the committed SQ counter passes of this
+    command (profiles/<tag>_pmc_sq*.csv, tools/pmc_run.sh).  issue_ceiling_GBps = input bytes / (VALU instructions x 4
+    cycles / (1024 SIMDs x clock)): what the chip would reach at this instruction count with every issue slot used."""
+    import csv
+
+    def means(name):
+        acc = {}
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+            if "tamp_compress" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+
+    for tag in (PROFILE_TAG, "r2"):
+        try:
+            m = means(f"{tag}_pmc_sq_counter_collection.csv")
+            m.update(means(f"{tag}_pmc_sq2_counter_collection.csv"))
+            cycles = m["GRBM_GUI_ACTIVE"] / 8.0  # per XCD
+            valu = m["SQ_INSTS_VALU"]
+        except Exception:
+            continue
+        clock_ghz = 2.4
+        return {
+            "valu_per_stream": round(valu / n_streams),
+            "salu_per_stream": round(m.get("SQ_INSTS_SALU", 0) / n_streams),
+            "valu_busy": round(m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 3),
+            "issue_ceiling_GBps": round(in_bytes / (valu * 4 / (1024 * clock_ghz * 1e9)) / 1e9, 1),
+            "issue_source": f"profiles/{tag}_pmc_sq{{,2}}_counter_collection.csv"
+                            + ("" if tag == PROFILE_TAG else " [STALE: captured on an earlier build of the kernel]"),
+        }
+    return {"valu_per_stream": None, "issue_source": "no committed SQ counter pass"}
 
 
 def _checker():
@@ -395,9 +447,9 @@ def also_v1_and_decode(shard, res, torch):
 
 
 def also_real_text(args, torch, np):
-    """Real text found on this machine (the metric's own corpus, enwik8, is not in the image): GB/s of input per corpus,
-    both formats, 16,384 x 4 KiB streams (the corpus repeated to fill them), with the first 512 streams of each checked
-    against the reference C."""
+    """Real text (the frozen fixtures of tests/golden/make_corpus.py; the metric's own corpus, enwik8, is not in the
+    image): GB/s of input per corpus, both formats, 16,384 x 4 KiB streams (the corpus repeated to fill them), with the
+    first 512 streams of each checked against the reference C."""
     import tamp_amd
     from tamp_amd import workloads as wl
 
@@ -508,21 +560,33 @@ def also_baseline_configs(torch, np):
     return out
 
 
-def corpus_pins(args, blob, torch, np):
+def corpus_pins(args, blob, torch, np, reference=None):
     """Whole-file pins of the reference for enwik8: the file as ONE stream, both formats, SHA-256 and size of the output
-    (tests/test_dataset_regression.py:38-43, README.md:266), plus the first 100 KB in the v1 format (README.md:336)."""
+    (tests/test_dataset_regression.py:38-43, README.md:266), plus the first 100 KB in the v1 format (README.md:336).
+    A file of another size has no published pin; with ``reference`` (a checker from oracle/) the same ONE-stream outputs
+    are compared with what the reference C produces for this very file (the 100,000,000-byte test of tests/)."""
     import tamp_amd
     from tamp_amd import workloads as wl
 
     pins = wl.ENWIK8_PINS
-    if len(blob) != pins["len"]:
+    is_enwik8_size = len(blob) == pins["len"]
+    if not is_enwik8_size and reference is None:
         return {"checked": False, "why": f"file is {len(blob)} B, enwik8 is {pins['len']} B: no whole-file pin applies"}
-    out = {"checked": True}
+    out = {"checked": True, "bytes": len(blob)}
     for ext in (False, True):
         r = tamp_amd.compress_batch([blob], window=10, literal=8, extended=ext)
         got = r.stream(0)
         tag = "extended" if ext else "v1"
-        out[tag] = {"size": len(got), "size_pin": pins[tag + "_size"], "sha256_matches_reference": hashlib.sha256(got).hexdigest() == pins[tag + "_sha256"]}
+        digest = hashlib.sha256(got).hexdigest()
+        out[tag] = {"size": len(got), "status": int(r.status[0]), "sha256": digest[:16]}
+        if is_enwik8_size:
+            out[tag].update(size_pin=pins[tag + "_size"], sha256_matches_reference=digest == pins[tag + "_sha256"])
+        if reference is not None:
+            flat = np.frombuffer(blob, dtype=np.uint8)
+            want = reference.compress_batch(flat, np.zeros(1, np.uint64), np.array([len(blob)], np.uint32), window=10,
+                                            literal=8, extended=ext).stream(0)
+            out[tag]["matches_checker"] = got == want
+            out[tag]["checker_size"] = len(want)
     sizes = {("extended" if ext else "v1"): len(tamp_amd.compress_batch([blob[:100_000]], window=10, literal=8,
                                                                           extended=ext).stream(0)) for ext in (False, True)}
     out["first_100k"] = dict(sizes, size_pin=pins["first_100k_v1_size"],

@@ -314,6 +314,11 @@ tamp_res tamp_amd_read_header(TampAmdConf *conf, const unsigned char *input, siz
 void tamp_amd_set_timing(int enabled);
 float tamp_amd_last_kernel_ms(void);
 
+/* Which compress kernel the most recent compress launch of this process used: "epoch" (tamp_compress_kernel.hpp, the
+ * default) or "tile" (tamp_compress_tile_kernel.hpp, opt-in with TAMP_AMD_ENCODER=tile); "" before the first launch.
+ * For tests and tuning: the bytes are the same either way. */
+const char *tamp_amd_last_encoder(void);
+
 #ifdef __cplusplus
 }
 #endif

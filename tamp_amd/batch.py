@@ -8,6 +8,7 @@ straight into the C ABI (include/tamp_amd.h).  CSR contract: stream ``i`` is
 from __future__ import annotations
 
 import ctypes as C
+import numbers
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -35,6 +36,7 @@ class BatchResult:
     in_consumed: object = None
     kernel_ms: float = -1.0
     _keep: object = None  # device tensors the asynchronous launch still reads (converted tables, the dictionary)
+    _ws_key: object = None  # (streams, capacity, device) when the slab may serve as the next call's workspace (``reuse=``)
 
     def stream(self, i: int) -> bytes:
         o, n = int(self.out_off[i]), int(self.out_len[i])
@@ -56,6 +58,11 @@ def _np_u8(x) -> np.ndarray:
     if isinstance(x, np.ndarray):
         return np.ascontiguousarray(x.reshape(-1), dtype=np.uint8)
     return np.frombuffer(bytes(x), dtype=np.uint8)
+
+
+def _is_int(x) -> bool:
+    """A plain integer capacity: Python or numpy integer scalars, not bool (numpy scalars are not ``int`` instances)."""
+    return isinstance(x, numbers.Integral) and not isinstance(x, bool)
 
 
 def _ptr(a):
@@ -86,7 +93,7 @@ def _slab_offsets(caps: np.ndarray):
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
                    dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
                    max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False,
-                   run_aware=None) -> BatchResult:
+                   run_aware=None, reuse=None) -> BatchResult:
     """Compress many independent streams in one launch.
 
     ``data`` is a list of bytes-likes (host), a flat numpy uint8 array + ``in_off``/``in_len`` (host), or a flat
@@ -96,6 +103,8 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     ``run_aware`` picks the kernel build (same bytes either way): True = the run-aware build (long runs listed once,
     most extended matches settled without a search: faster for streams of 1 KiB and more), False = the lean build
     (faster for short messages), None = the library decides by stream length (``max_in_len`` >= 1 KiB -> run-aware).
+    ``reuse`` (device batches with an integer ``out_cap``): the result of an earlier call with the same stream count and
+    capacity on the same device; its output slab and tables are overwritten instead of allocating new ones.
     """
     lib = _lib.load()
     conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching, run_aware)
@@ -108,9 +117,17 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
 
         n = int(in_len.numel())
         dev = data.device
-        if out_cap is None or isinstance(out_cap, int):
-            if isinstance(out_cap, int):
-                cap1 = out_cap  # one capacity for every stream: no device round trip to lay the slabs out
+        ws = None
+        if reuse is not None and out_cap is not None and _is_int(out_cap) and reuse._ws_key == (n, int(out_cap), str(dev)):
+            # steady-state callers (one launch per step on the same shapes): the output slab and its tables of the
+            # previous call are written again -- no allocation, no fill kernels, nothing on the host but the launch
+            ws = reuse
+            out, out_off_t, out_len_t, status_t, out_cap_t = ws.out, ws.out_off, ws.out_len, ws.status, ws._keep[3]
+        elif out_cap is None or _is_int(out_cap):
+            if _is_int(out_cap):
+                cap1 = int(out_cap)  # one capacity for every stream: no device round trip to lay the slabs out
+                # (max_in_len stays as given: 0 = unknown, which AUTO reads as "long streams" -> the run-aware build;
+                # pass max_in_len for batches of short messages)
             else:
                 if not max_in_len:
                     max_in_len = int(in_len.max().item()) if n else 0
@@ -122,9 +139,10 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
             out_cap_t = out_cap.to(device=dev, dtype=torch.int32)
             out_off_t = torch.cumsum(out_cap_t.to(torch.int64), 0) - out_cap_t.to(torch.int64)
             total = int(out_cap_t.to(torch.int64).sum().item())
-        out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-        out_len_t = torch.empty(n, dtype=torch.int32, device=dev)
-        status_t = torch.empty(n, dtype=torch.int8, device=dev)
+        if ws is None:
+            out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+            out_len_t = torch.empty(n, dtype=torch.int32, device=dev)
+            status_t = torch.empty(n, dtype=torch.int8, device=dev)
         dict_t = None
         if dictionary is not None:
             dict_t = dictionary if _is_torch(dictionary) else torch.frombuffer(bytearray(dictionary), dtype=torch.uint8).to(dev)
@@ -137,7 +155,9 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
                                      dev.index or 0, C.c_void_p(st))
         _lib.check_launch(rc)
         ms = lib.tamp_amd_last_kernel_ms() if timing else -1.0
-        return BatchResult(out, out_off_t, out_len_t, status_t, None, ms, (data, in_off_t, in_len_t, out_cap_t, dict_t))
+        res = BatchResult(out, out_off_t, out_len_t, status_t, None, ms, (data, in_off_t, in_len_t, out_cap_t, dict_t))
+        res._ws_key = (n, int(out_cap), str(dev)) if (out_cap is not None and _is_int(out_cap)) else None
+        return res
 
     if in_off is None:
         flat, in_off, in_len = pack_streams(data)
@@ -148,6 +168,8 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     n = len(in_len)
     if out_cap is None:
         out_cap = np.array([compress_bound(int(x), literal, dictionary_reset) for x in in_len], dtype=np.uint32)
+    elif _is_int(out_cap):
+        out_cap = np.full(n, int(out_cap), dtype=np.uint32)
     out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
     out_off, total = _slab_offsets(out_cap)
     out = np.zeros(total + 1, dtype=np.uint8)
@@ -184,7 +206,8 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
 
         n = int(in_len.numel())
         dev = data.device
-        if isinstance(out_cap, int):
+        if _is_int(out_cap):
+            out_cap = int(out_cap)
             out_cap_t = torch.full((n,), out_cap, dtype=torch.int32, device=dev)
             out_off_t = torch.arange(n, dtype=torch.int64, device=dev) * out_cap
             total = n * out_cap
@@ -217,8 +240,8 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
         in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
         in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
     n = len(in_len)
-    if isinstance(out_cap, int):
-        out_cap = np.full(n, out_cap, dtype=np.uint32)
+    if _is_int(out_cap):
+        out_cap = np.full(n, int(out_cap), dtype=np.uint32)
     out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
     out_off, total = _slab_offsets(out_cap)
     out = np.zeros(total + 1, dtype=np.uint8)

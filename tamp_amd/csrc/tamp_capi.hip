@@ -88,6 +88,7 @@ thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
 thread_local bool t_ev_valid = false;
 
 thread_local char t_last_error[512] = "";
+std::atomic<const char*> g_last_encoder{""};  // tamp_amd_last_encoder()
 unsigned long long* g_prof = nullptr;  // -DTAMP_PROF builds: device buffer of per-phase cycle sums
 
 #define HIP_OK(expr)                                                                                      \
@@ -281,6 +282,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
             auto tk = conf->window == 10 ? tamp_compress_tile_kernel<10>
                       : conf->window == 9 ? tamp_compress_tile_kernel<9> : tamp_compress_tile_kernel<8>;
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL.total));
+            g_last_encoder.store("tile");
             timing_begin(st);
             for (size_t first = 0; first < n_streams; first += grid) {
                 a.first_stream = (uint32_t)first;
@@ -302,6 +304,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     if (threads == 64 && packed && !a.lazy && !runlist && !getenv("TAMP_AMD_NOSHORT")) kernel = tamp_compress_kernel<true, false, false, 0, 9>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
+    g_last_encoder.store("epoch");
     timing_begin(st);
 #ifdef TAMP_STREAM_LOOP
     {   // persistent grid: what the device holds at once, streams handed out by a counter
@@ -1031,6 +1034,8 @@ void tamp_amd_host_free(void* p) {
 }
 
 void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
+
+const char* tamp_amd_last_encoder(void) { return g_last_encoder.load(); }
 
 float tamp_amd_last_kernel_ms(void) {
     if (!t_ev_valid) return -1.0f;

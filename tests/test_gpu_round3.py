@@ -1,0 +1,145 @@
+"""Round-3 GPU tests: very long single streams (the one-workgroup path bench.corpus_pins takes for enwik8), the
+one-process N-shard launch path of bench.py, and the opt-in tile-ring encoder.  All `-m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import tamp_amd
+
+    return tamp_amd
+
+
+@pytest.fixture(scope="module")
+def checker():
+    from oracle.checker import Oracle, Ref
+
+    return Ref() if Ref.available() else Oracle()
+
+
+def _tiled(nbytes: int) -> bytes:
+    """Real text of exactly ``nbytes``: the frozen prose and Python corpora alternating, cut at odd places so that the
+    copies do not line up with the 4 KiB / 64-position grids of the kernels."""
+    from tamp_amd import workloads as wl
+
+    prose, py = wl.real_text("prose"), wl.real_text("python")
+    parts, total, k = [], 0, 0
+    while total < nbytes:
+        src = prose if k % 2 == 0 else py
+        cut = len(src) - 4099 * (k % 7) - 1
+        parts.append(src[:cut])
+        total += cut
+        k += 1
+    return b"".join(parts)[:nbytes]
+
+
+def test_one_16_mib_stream_matches_reference(ta, checker):
+    """ONE stream of 16 MiB through one workgroup, both formats, byte for byte against the reference C (the largest
+    one-shot stream of round 2 was 300 KB)."""
+    blob = _tiled(16 << 20)
+    flat = np.frombuffer(blob, dtype=np.uint8)
+    off, ln = np.zeros(1, np.uint64), np.array([len(blob)], np.uint32)
+    for ext in (True, False):
+        want = checker.compress_batch(flat, off, ln, window=10, literal=8, extended=ext)
+        got = ta.compress_batch(flat, off, ln, window=10, literal=8, extended=ext)
+        assert int(got.status[0]) == 0 and int(want.status[0]) == 0
+        assert got.stream(0) == want.stream(0), f"16 MiB stream differs (extended={ext})"
+        back = ta.decompress_batch([want.stream(0)], out_cap=len(blob) + 8)
+        assert int(back.status[0]) == 2 and back.stream(0) == blob
+
+
+def test_corpus_pins_path_on_a_100_000_000_byte_file(ta, checker):
+    """bench.corpus_pins -- the code that will claim the enwik8 whole-file pins -- on a file of enwik8's size: one
+    100,000,000-byte stream per format, compared with the reference C on the same bytes (a tiled real-text file has no
+    published pin, so `sha256_matches_reference` must come out False and `matches_checker` True)."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    blob = _tiled(100_000_000)
+    out = bench.corpus_pins(None, blob, torch, np, reference=checker)
+    assert out["checked"] is True and out["bytes"] == 100_000_000
+    for tag in ("v1", "extended"):
+        assert out[tag]["status"] == 0
+        assert out[tag]["matches_checker"] is True, (tag, out[tag])
+        assert out[tag]["sha256_matches_reference"] is False  # not enwik8: the published pin must not be claimed
+        assert out[tag]["size"] == out[tag]["checker_size"]
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_one_process_eight_shards_keep_the_device_fed():
+    """`python bench.py --gpus 8` as ONE process issuing eight launches per step (north_star's launch model), all shards on
+    this box's one device: the wall clock of a step must not exceed the kernels' own time by more than 5 % -- a host-side
+    launch bottleneck (allocation, fill kernels, Python per shard) would show up here -- and the per-shard enqueue cost
+    is reported."""
+    line = _bench(["--gpus", "8", "--streams", "8192", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                  {"TAMP_BENCH_ONE_DEVICE": "1"})
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["streams_total"] == 8 * 8192 and cfg["all_streams_ok"]
+    assert cfg["host_launch_us_per_shard"] > 0
+    assert line["ms_per_step"] <= 1.05 * cfg["sum_kernel_ms_per_step"], (line["ms_per_step"], cfg)
+    # a launch must cost the host far less than the kernel it starts (8,192 streams run ~0.9 ms)
+    assert cfg["host_launch_us_per_shard"] < 300, cfg
+
+
+def test_corpus_strong_scaling_path_with_four_shards(tmp_path):
+    """--corpus with --gpus 4 (strong scaling: contiguous stream ranges balanced by bytes), all shards on one device."""
+    from tamp_amd import workloads as wl
+
+    p = tmp_path / "corpus.txt"
+    p.write_bytes(wl.real_text("prose")[: (2 << 20) + 321])
+    line = _bench(["--gpus", "4", "--corpus", str(p), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                  {"TAMP_BENCH_ONE_DEVICE": "1"})
+    assert line["scaling"] == "strong" and line["n_gpus"] == 4
+    assert line["config"]["streams_total"] == 513 and line["config"]["all_streams_ok"]
+    assert line["ms_per_step"] <= 1.05 * line["config"]["sum_kernel_ms_per_step"] + 0.2
+
+
+def test_tile_ring_encoder_matches_reference(ta, checker):
+    """TAMP_AMD_ENCODER=tile (tamp_compress_tile_kernel.hpp, opt-in): same bytes as the reference on real text cut
+    into 4 KiB streams, ragged lengths, runs and periodic data, windows 2^8..2^10, both formats."""
+    from tamp_amd import _lib, workloads as wl
+
+    os.environ["TAMP_AMD_ENCODER"] = "tile"
+    try:
+        rng = np.random.default_rng(11)
+        prose = wl.real_text("prose")
+        lens = np.concatenate([np.arange(0, 24), rng.integers(1, 9000, 120)]).astype(np.uint32)
+        off = np.zeros(len(lens), np.uint64)
+        off[1:] = np.cumsum(lens[:-1])
+        ragged = (np.frombuffer(prose[: int(lens.sum())], dtype=np.uint8), off, lens)
+        specials = [bytes(5000), b"ab" * 3000, bytes([7]) * 300 + b"xyz" + bytes([7]) * 3000, (b"x" * 20 + b"hello world ") * 300,
+                    bytes(rng.integers(0, 4, 6000, dtype=np.uint8)), bytes(rng.integers(0, 256, 6000, dtype=np.uint8))]
+        sl = np.array([len(x) for x in specials], np.uint32)
+        so = np.zeros(len(sl), np.uint64)
+        so[1:] = np.cumsum(sl[:-1])
+        cases = [ragged, (np.frombuffer(b"".join(specials), dtype=np.uint8), so, sl)]
+        for name in ("prose", "python"):
+            cases.append(wl.split_fixed(wl.real_text(name)[: (1 << 20) + 777], 4096))
+        for flat, o, l in cases:
+            for window in (8, 9, 10):
+                for ext in (True, False):
+                    want = checker.compress_batch(flat, o, l, window=window, literal=8, extended=ext, threads=8)
+                    got = ta.compress_batch(flat, o, l, window=window, literal=8, extended=ext, max_in_len=int(l.max()))
+                    for i in range(len(l)):
+                        assert got.stream(i) == want.stream(i) and int(got.status[i]) == int(want.status[i]), (window, ext, i)
+                    assert _lib.load().tamp_amd_last_encoder() == b"tile"  # (and not the default kernel under another name)
+    finally:
+        del os.environ["TAMP_AMD_ENCODER"]
