@@ -314,6 +314,13 @@ tamp_res tamp_amd_read_header(TampAmdConf *conf, const unsigned char *input, siz
 void tamp_amd_set_timing(int enabled);
 float tamp_amd_last_kernel_ms(void);
 
+/* Releases the device scratch the library keeps between calls on `device` -- decoder window slabs and the split
+ * decoder's token-record slab, one set per HIP stream that ever decoded (up to a quarter of the free device memory, 4 GiB
+ * at most, per stream).  Synchronises those streams first.  Returns the bytes released or a negative TAMP_AMD_* code.
+ * (The library itself falls back to decoders without scratch when an allocation fails; this call is for callers that
+ * want the memory back.) */
+long long tamp_amd_trim(int device);
+
 /* Which compress kernel the most recent compress launch of this process used: "epoch" (tamp_compress_kernel.hpp, the
  * default) or "tile" (tamp_compress_tile_kernel.hpp, opt-in with TAMP_AMD_ENCODER=tile); "" before the first launch.
  * For tests and tuning: the bytes are the same either way. */

@@ -19,7 +19,7 @@ class ExcessBitsError(Exception):
 
 
 from ._lib import NativeLibraryError  # noqa: E402
-from .batch import BatchResult, DecoderBatch, EncoderBatch, compress_batch, compress_bound, decompress_batch, pack_streams  # noqa: E402
+from .batch import BatchResult, DecoderBatch, EncoderBatch, compress_batch, compress_bound, decompress_batch, pack_streams, trim  # noqa: E402
 from .codec import (  # noqa: E402
     Compressor,
     Decompressor,
@@ -34,7 +34,7 @@ from .sharding import partition_streams, shard_for_rank  # noqa: E402
 
 __all__ = [
     "ExcessBitsError", "NativeLibraryError", "BatchResult", "compress", "decompress", "compress_batch",
-    "decompress_batch", "compress_bound", "pack_streams", "DecoderBatch", "EncoderBatch", "Compressor", "Decompressor", "TextCompressor",
+    "decompress_batch", "compress_bound", "pack_streams", "trim", "DecoderBatch", "EncoderBatch", "Compressor", "Decompressor", "TextCompressor",
     "TextDecompressor", "open", "initialize_dictionary", "compute_min_pattern_size", "bit_size",
     "partition_streams", "shard_for_rank",
 ]

@@ -43,6 +43,7 @@ SYMBOLS = (
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
     "tamp_amd_last_encoder",
+    "tamp_amd_trim",
     "tamp_amd_host_alloc",
     "tamp_amd_host_free",
     # include/tamp_compat.h: the reference's own symbol names
@@ -148,6 +149,8 @@ def load() -> C.CDLL:
     lib.tamp_amd_set_timing.restype = None
     lib.tamp_amd_last_kernel_ms.restype = C.c_float
     lib.tamp_amd_last_encoder.restype = C.c_char_p
+    lib.tamp_amd_trim.argtypes = [i32]
+    lib.tamp_amd_trim.restype = C.c_longlong
     lib.tamp_amd_host_alloc.argtypes = [sz]
     lib.tamp_amd_host_alloc.restype = vp
     lib.tamp_amd_host_free.argtypes = [vp]

@@ -90,6 +90,15 @@ def _slab_offsets(caps: np.ndarray):
     return offs, int(caps.astype(np.uint64).sum())
 
 
+def trim(device: int = 0) -> int:
+    """Release the device scratch the library keeps between calls on ``device`` (decoder window slabs, the split decoder's
+    record slab); returns the bytes released.  ``tamp_amd_trim`` of the C ABI."""
+    freed = int(_lib.load().tamp_amd_trim(device))
+    if freed < 0:
+        _lib.check_launch(freed)
+    return freed
+
+
 def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal: int = 8, extended: bool = True,
                    dictionary=None, dictionary_reset: bool = False, lazy_matching: bool = False, out_cap=None,
                    max_in_len: int = 0, device: int = 0, stream=None, timing: bool = False,

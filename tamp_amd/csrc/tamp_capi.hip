@@ -77,6 +77,21 @@ struct DeviceCtx {
                 return e;
             }
         } in[kDepth], out[kDepth], meta[kDepth], dict;
+        // pinned host staging for output slabs that do not tile their extent (gaps, padding, permuted offsets): the chunk's
+        // extent comes back in ONE transfer and the produced bytes are placed by the host
+        struct Pinned {
+            void* p = nullptr;
+            size_t bytes = 0;
+            hipError_t need(size_t n) {
+                if (n <= bytes) return hipSuccess;
+                if (p) (void)hipHostFree(p);
+                p = nullptr, bytes = 0;
+                n += n / 4 + 4096;
+                hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+                if (e == hipSuccess) bytes = n;
+                return e;
+            }
+        } stage[kDepth];
     } pipe;
 };
 
@@ -433,29 +448,46 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         size_t slice_log2 = 18;
         if (const char* e = getenv("TAMP_AMD_SPLIT_SLICE_LOG2")) { const int v = atoi(e); if (v >= 12 && v <= 22) slice_log2 = (size_t)v; }
         size_t slice = std::min<size_t>(n_streams, (size_t)1 << slice_log2);
+        const size_t per = (size_t)sa.tokcap * 4 + 4 + kSplitMaxLag * 8;
         {
-            size_t budget = (size_t)8 << 30;
+            // scratch budget: a quarter of what the device has free right now, 4 GiB at most (callers that fill HBM with
+            // their own batches keep most of it); TAMP_AMD_SPLIT_SCRATCH_MB overrides
+            size_t budget = (size_t)4 << 30, free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 4);
+            else (void)hipGetLastError();
             if (const char* e = getenv("TAMP_AMD_SPLIT_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
-            const size_t per = (size_t)sa.tokcap * 4 + 4 + kSplitMaxLag * 8;
             slice = std::min(slice, std::max<size_t>(budget / per, 4096));
         }
-        const size_t b_recs = slice * sa.tokcap * 4, b_meta = slice * 4, b_lag = slice * kSplitMaxLag * 8;
-        const size_t need = b_recs + b_meta + b_lag + n_streams + 64;
+        // The slab is kept per HIP stream between calls (tamp_amd_trim() releases it).  If the device cannot supply it the
+        // slice is halved down to 4,096 streams, and below that the batch goes to the lane / wave decoders, which need
+        // little or no scratch: an allocation failure here must not fail a call that another decoder can serve.
         uint8_t* base = nullptr;
+        size_t b_recs = 0, b_meta = 0, b_lag = 0;
         {
             std::lock_guard<std::mutex> lock(g_mu);
             DeviceCtx::Slab& slab = ctx->slabs[st];
-            if (slab.split_bytes < need) {
+            for (;;) {
+                b_recs = slice * sa.tokcap * 4, b_meta = slice * 4, b_lag = slice * kSplitMaxLag * 8;
+                const size_t need = b_recs + b_meta + b_lag + n_streams + 64;
+                if (slab.split_bytes >= need) break;
                 if (slab.split) {
                     HIP_OK(hipStreamSynchronize(st));
                     HIP_OK(hipFree(slab.split));
                     slab.split = nullptr, slab.split_bytes = 0;
                 }
-                HIP_OK(hipMalloc(&slab.split, need));
-                slab.split_bytes = need;
+                const bool deny = getenv("TAMP_AMD_SPLIT_FAIL_ABOVE") && need > (size_t)atol(getenv("TAMP_AMD_SPLIT_FAIL_ABOVE"));  // (tests)
+                if (!deny && hipMalloc(&slab.split, need) == hipSuccess) {
+                    slab.split_bytes = need;
+                    break;
+                }
+                (void)hipGetLastError();  // clear the sticky out-of-memory error
+                slab.split = nullptr;
+                if (slice <= 4096) { slice = 0; break; }
+                slice = std::max<size_t>(slice / 2, 4096);
             }
             base = slab.split;
         }
+        if (slice) {
         sa.recs = reinterpret_cast<uint32_t*>(base);
         sa.meta = reinterpret_cast<uint32_t*>(base + b_recs);
         sa.lag = reinterpret_cast<uint32_t*>(base + b_recs + b_meta);
@@ -488,6 +520,7 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         timing_end(st);
         HIP_OK(hipGetLastError());
         return TAMP_OK;
+        }  // (no scratch to be had: fall through to the lane / wave decoders)
     }
     // Decoder choice: one wavefront per stream (scalar token loop, window in LDS, 64-lane copies) unless the batch is
     // a very large number of streams, where one lane per stream fills the chip and avoids per-stream set-up.
@@ -806,7 +839,18 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
         HIP_OK(hipMemcpyAsync(b.status + ch.i0, s.status, cnt, hipMemcpyDeviceToHost, st));
         if (b.in_consumed) HIP_OK(hipMemcpyAsync(b.in_consumed + ch.i0, s.in_consumed, cnt * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        if (!ch.out_packed) {
+        if (!ch.out_packed && ch.out_hi > ch.out_lo && !getenv("TAMP_AMD_NO_STAGED_COPYBACK") &&
+            P.stage[j].need(ch.out_hi - ch.out_lo) == hipSuccess) {
+            // One device-to-pinned transfer of the chunk's whole extent, then exactly the produced bytes of every stream
+            // placed by the host: bytes between and behind the slabs are never written.  (One hipMemcpyAsync per stream,
+            // the form this replaces and the fallback below, is orders of magnitude slower for 10^5+ padded slabs.)
+            uint8_t* stg = static_cast<uint8_t*>(P.stage[j].p);
+            HIP_OK(hipMemcpyAsync(stg, P.out[j].p, ch.out_hi - ch.out_lo, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            for (size_t i = ch.i0; i < ch.i1; i++)
+                if (b.out_len[i]) memcpy(b.out + b.out_off[i], stg + (b.out_off[i] - ch.out_lo), b.out_len[i]);
+        } else if (!ch.out_packed) {
+            (void)hipGetLastError();  // (a failed pinned allocation must not poison later calls)
             // exactly the produced bytes of every stream, runs of touching full slabs merged into one transfer
             const uint8_t* dev_out = static_cast<const uint8_t*>(P.out[j].p);
             size_t i = ch.i0;
@@ -1036,6 +1080,26 @@ void tamp_amd_host_free(void* p) {
 void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
 
 const char* tamp_amd_last_encoder(void) { return g_last_encoder.load(); }
+
+// Release the scratch the library keeps between calls on `device` (decoder window slabs, split-decoder records, header
+// pre-pass words: one set per HIP stream that ever decoded; the staging of the host-memory pipeline stays).  Every stream
+// that owns a slab is synchronised first.  Returns the number of bytes released, or a negative TAMP_AMD_* code.
+long long tamp_amd_trim(int device) {
+    DeviceCtx* ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc != TAMP_OK) return rc;
+    long long freed = 0;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto& kv : ctx->slabs) {
+        DeviceCtx::Slab& slab = kv.second;
+        std::lock_guard<std::mutex> call_lock(slab.launch_mu);
+        if (!slab.p && !slab.split) continue;
+        if (hipStreamSynchronize(kv.first) != hipSuccess) (void)hipGetLastError();
+        if (slab.p) { (void)hipFree(slab.p); freed += (long long)slab.bytes; slab.p = nullptr, slab.bytes = 0; }
+        if (slab.split) { (void)hipFree(slab.split); freed += (long long)slab.split_bytes; slab.split = nullptr, slab.split_bytes = 0; }
+    }
+    return freed;
+}
 
 float tamp_amd_last_kernel_ms(void) {
     if (!t_ev_valid) return -1.0f;
@@ -1524,7 +1588,9 @@ tamp_res tamp_compressor_compress_and_flush_cb(TampCompressor* compressor, unsig
         if (r == TAMP_OK && input_consumed_size) *input_consumed_size = input_size;
     } else if (input_size > kCompatPiece) {  // compressor.c:815-845 as it is written there: compress, then flush
         size_t consumed = 0, written = 0, w2 = 0;
-        r = tamp_compressor_compress_cb(compressor, output, output_size, &written, input, input_size, &consumed, nullptr, nullptr);
+        // (the caller's callback rides along: it sees the progress of every piece and a non-zero return aborts the call
+        // there, as in the reference, where it runs per poll)
+        r = tamp_compressor_compress_cb(compressor, output, output_size, &written, input, input_size, &consumed, callback, user_data);
         if (r == TAMP_OK && consumed == input_size) {
             r = tamp_compressor_flush(compressor, output + written, output_size - written, &w2, write_token);
             written += w2;

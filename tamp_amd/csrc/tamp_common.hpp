@@ -68,6 +68,12 @@ __device__ __forceinline__ uint32_t lds_u32_unaligned(const uint8_t* base, uint3
 // six ds_bpermute round trips through the LDS pipe with their lane-index arithmetic: __shfl_up compiles to the latter).
 // row_shr:n keeps `old` (the identity) where the source lane lies outside the 16-lane row; row_bcast:15 / :31 hand the
 // last lane of a row / of the lower half to the rows the row mask selects.
+// The DPP controls used below (row_bcast:15 / :31 here, wave_shr:1 in the resolve kernel) exist on the GFX9 family
+// (GCN / CDNA, 64-wide wavefronts) only -- which is all this library builds for.  Call sites must be wave-uniform with
+// every lane enabled: the row broadcasts read lanes that a partial EXEC mask would leave stale.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "tamp_amd device code is written for gfx9-family wave64 targets (gfx950); its DPP scans have no gfx10+ form"
+#endif
 template <class Op>
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t identity, Op op) {
     x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1

@@ -189,9 +189,14 @@ def test_host_copy_back_touches_only_produced_bytes(ta, oracle, monkeypatch):
         out = np.full(n * stride + 8, 0xEE, dtype=np.uint8)
         out_len = np.zeros(n, np.uint32)
         status = np.zeros(n, np.int8)
-        for fan in ("0", "3"):  # single device path, then TAMP_AMD_ALL_DEVICES with three shards on the one device
+        # single device path (staged copy-back, then the per-stream fallback), then TAMP_AMD_ALL_DEVICES with three shards
+        for fan, staged in (("0", True), ("0", False), ("3", True)):
             out[:] = 0xEE
             monkeypatch.setenv("TAMP_AMD_FANOUT", fan)
+            if staged:
+                monkeypatch.delenv("TAMP_AMD_NO_STAGED_COPYBACK", raising=False)
+            else:
+                monkeypatch.setenv("TAMP_AMD_NO_STAGED_COPYBACK", "1")
             p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
             rc = lib.tamp_batch_compress(C.byref(conf), None, p(rows), p(off), p(ln), p(out), p(out_off), p(cap), p(out_len),
                                          p(status), n, slen, _lib.MEM_HOST, -1 if fan != "0" else 0, None)

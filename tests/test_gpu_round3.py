@@ -143,3 +143,63 @@ def test_tile_ring_encoder_matches_reference(ta, checker):
                     assert _lib.load().tamp_amd_last_encoder() == b"tile"  # (and not the default kernel under another name)
     finally:
         del os.environ["TAMP_AMD_ENCODER"]
+
+
+def test_split_decoder_scratch_failure_falls_back_and_trim_releases(ta, checker, monkeypatch):
+    """the split decoder's record slab (hundreds of MB for 4 KiB streams) is cached per HIP stream; when the
+    device cannot supply it the slice shrinks, and below 4,096 streams the batch is decoded by the lane / wave decoders
+    instead of failing the call.  tamp_amd_trim() hands the cached slabs back."""
+    from tamp_amd import workloads as wl
+
+    n, L = 6000, 4096
+    rows = wl.synth_text(n, L)
+    off, ln = wl.csr_for_fixed(n, L)
+    comp = ta.compress_batch(rows.reshape(-1), off, ln, window=10, literal=8, max_in_len=L)
+    streams = [comp.stream(i) for i in range(n)]
+
+    def decode_and_check():
+        back = ta.decompress_batch(streams, out_cap=L + 8)
+        assert (np.asarray(back.status) == 2).all()
+        for i in range(0, n, 37):
+            assert back.stream(i) == rows[i].tobytes(), i
+
+    ta.trim(0)
+    decode_and_check()                       # split decoder, slab allocated
+    assert ta.trim(0) > 0                    # ... and released
+    assert ta.trim(0) == 0
+    monkeypatch.setenv("TAMP_AMD_SPLIT_FAIL_ABOVE", str(40 << 20))  # every slab above 40 MB is refused: the slice halves
+    decode_and_check()
+    monkeypatch.setenv("TAMP_AMD_SPLIT_FAIL_ABOVE", "1")            # nothing can be allocated: lane / wave decoders
+    ta.trim(0)
+    decode_and_check()
+    monkeypatch.delenv("TAMP_AMD_SPLIT_FAIL_ABOVE")
+    decode_and_check()
+
+
+def test_numpy_integer_capacities_and_workspace_reuse(ta, checker):
+    """out_cap as a numpy integer scalar (`isinstance(out_cap, int)` sent it down the tensor path), and the
+    `reuse=` workspace of steady-state callers: same bytes, same buffers."""
+    import torch
+
+    from tamp_amd import workloads as wl
+
+    n, L = 512, 4096
+    rows = wl.synth_text(n, L)
+    off, ln = wl.csr_for_fixed(n, L)
+    dev = torch.device("cuda:0")
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off_t, len_t = torch.from_numpy(off.astype(np.int64)).to(dev), torch.from_numpy(ln.astype(np.int32)).to(dev)
+    want = checker.compress_batch(rows.reshape(-1), off, ln, window=10, literal=8, extended=True, threads=8)
+    cap = np.int64(ta.compress_bound(L, 8))
+    r1 = ta.compress_batch(data, off_t, len_t, out_cap=cap, max_in_len=L)
+    r2 = ta.compress_batch(data, off_t, len_t, out_cap=np.uint32(cap), max_in_len=L, reuse=r1)
+    torch.cuda.synchronize()
+    assert r2.out.data_ptr() == r1.out.data_ptr() and r2.out_len.data_ptr() == r1.out_len.data_ptr()
+    for i in range(n):
+        assert r2.stream(i) == want.stream(i)
+    with pytest.raises((TypeError, ValueError, AttributeError)):
+        ta.compress_batch(data, off_t, len_t, out_cap=True, max_in_len=L)  # bool is not a capacity
+    back = ta.decompress_batch(r2.out, r2.out_off, r2.out_len, out_cap=np.int32(L + 8))
+    assert bool((back.status == 2).all().item())
+    host = ta.compress_batch(rows.reshape(-1), off, ln, out_cap=np.int64(cap), max_in_len=L)  # host path, integer capacity
+    assert host.stream(5) == want.stream(5)
