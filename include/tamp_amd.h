@@ -304,6 +304,35 @@ tamp_res tamp_amd_compress_segment(const TampAmdConf *conf, int emit_header, int
                                    unsigned char *output, size_t output_size, size_t *output_written_size,
                                    const unsigned char *input, size_t input_size, int *token_written, int device);
 
+/*
+ * One PIECE of a stream -- a tamp_compressor_compress call on an object that lives on the host as (window_state,
+ * *window_pos, *carry).  With finish = 0 the piece ends exactly as the reference's call does (compressor.c:681-722: every
+ * byte is taken, parse steps run only while the 16-byte ring is full, whole output bytes leave, nothing is drained) and
+ * *carry receives what the reference's object still holds: a run or extended match that is still growing
+ * (compressor.h rle_count, extended_match_count / _position), up to 7 pending output bits, up to 15 unparsed input
+ * bytes.  The next piece continues from it (resume = 1).  finish = 1 ends the segment like tamp_amd_compress_segment
+ * (tamp_compressor_flush with write_token = flush_token) and clears the carry.  This is what bounded-memory writers are
+ * built from: tamp_amd.Compressor.write() sends a piece whenever it has gathered enough and returns the bytes written,
+ * as tamp/_c_compressor.pyx:74-118 does.  Not offered with conf->lazy_matching (the cached match of compressor.c:576-619
+ * is not carried): TAMP_AMD_BAD_ARGUMENT.  Give a piece tamp_amd_compress_bound(input_size + 271, ...) bytes of room;
+ * TAMP_OUTPUT_FULL leaves window_state / carry as they were.
+ */
+typedef struct TampAmdCarry {
+    uint8_t rle_count;   /* bytes consumed by a run that has not ended yet */
+    uint8_t ext_count;   /* bytes consumed by an extended match that has not ended yet ... */
+    uint16_t ext_pos;    /* ... and its window position */
+    uint8_t bit_count;   /* output bits not written yet: 0..7 on return; up to 31 accepted on entry (a reference object
+                            sits on its last token's bits until the next poll, compressor.c:549-551) */
+    uint8_t tail_len;    /* 0..16 input bytes taken but not parsed yet (0..15 on return) */
+    uint16_t reserved;
+    uint32_t bits;       /* the pending bits, left aligned: first one in bit 31 */
+    uint8_t tail[16];
+} TampAmdCarry;
+tamp_res tamp_amd_compress_piece(const TampAmdConf *conf, int emit_header, int append_marker, int resume, int finish,
+                                 int flush_token, unsigned char *window_state, uint16_t *window_pos, TampAmdCarry *carry,
+                                 unsigned char *output, size_t output_size, size_t *output_written_size,
+                                 const unsigned char *input, size_t input_size, int *token_written, int device);
+
 /* Replaces tamp_decompressor_read_header (decompressor.h:67, decompressor.c:276-297): host-side header parse. */
 tamp_res tamp_amd_read_header(TampAmdConf *conf, const unsigned char *input, size_t input_size,
                               size_t *input_consumed_size);

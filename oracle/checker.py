@@ -284,9 +284,10 @@ class Ref(_Base):
         L.ref_stream_free.argtypes = [C.c_void_p]
 
     def stream_script(self, ops, *, window=10, literal=8, extended=True, dictionary=None, dictionary_reset=False,
-                      append=False, lazy_matching=False):
+                      append=False, lazy_matching=False, counts=None):
         """Replay ``ops`` -- ("write", bytes) | ("flush", write_token) | ("reset",) | ("close",) -- on ONE reference
-        compressor object, the way tamp/_c_compressor.pyx drives it.  Returns (res, bytes emitted so far)."""
+        compressor object, the way tamp/_c_compressor.pyx drives it.  Returns (res, bytes emitted so far); ``counts`` (a
+        list) receives the bytes each op wrote."""
         d = _u8(dictionary) if dictionary is not None else None
         res = C.c_int(0)
         h = self.lib.ref_stream_new(window, literal, int(dictionary is not None), int(extended), int(dictionary_reset),
@@ -311,6 +312,8 @@ class Ref(_Base):
                 else:
                     raise ValueError(op[0])
                 emitted += out[: n.value].tobytes()
+                if counts is not None:
+                    counts.append(int(n.value))
                 if r < 0:
                     return r, bytes(emitted)
             return 0, bytes(emitted)

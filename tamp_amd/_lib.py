@@ -39,6 +39,7 @@ SYMBOLS = (
     "tamp_amd_compress",
     "tamp_amd_decompress",
     "tamp_amd_compress_segment",
+    "tamp_amd_compress_piece",
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
@@ -80,6 +81,20 @@ class TampAmdConf(C.Structure):
         ("lazy_matching", C.c_uint8),
         ("input_hint", C.c_uint8),  # 0 auto, 1 plain, 2 run-aware build (include/tamp_amd.h TAMP_AMD_HINT_*)
         ("reserved", C.c_uint8),
+    ]
+
+
+class TampAmdCarry(C.Structure):
+    """include/tamp_amd.h TampAmdCarry: what a compressor object holds between two pieces that no flush separates."""
+    _fields_ = [
+        ("rle_count", C.c_uint8),
+        ("ext_count", C.c_uint8),
+        ("ext_pos", C.c_uint16),
+        ("bit_count", C.c_uint8),
+        ("tail_len", C.c_uint8),
+        ("reserved", C.c_uint16),
+        ("bits", C.c_uint32),
+        ("tail", C.c_uint8 * 16),
     ]
 
 
@@ -143,6 +158,9 @@ def load() -> C.CDLL:
     lib.tamp_amd_compress_segment.argtypes = [C.POINTER(TampAmdConf), i32, i32, i32, i32, vp, C.POINTER(C.c_uint16), vp, sz,
                                               C.POINTER(sz), vp, sz, C.POINTER(i32), i32]
     lib.tamp_amd_compress_segment.restype = C.c_int8
+    lib.tamp_amd_compress_piece.argtypes = [C.POINTER(TampAmdConf), i32, i32, i32, i32, i32, vp, C.POINTER(C.c_uint16),
+                                            C.POINTER(TampAmdCarry), vp, sz, C.POINTER(sz), vp, sz, C.POINTER(i32), i32]
+    lib.tamp_amd_compress_piece.restype = C.c_int8
     lib.tamp_amd_read_header.argtypes = [C.POINTER(TampAmdConf), vp, sz, C.POINTER(sz)]
     lib.tamp_amd_read_header.restype = C.c_int8
     lib.tamp_amd_set_timing.argtypes = [i32]

@@ -46,13 +46,20 @@ def _raise_for(res: int):
 
 
 class Compressor:
-    """``tamp.Compressor`` (tamp/_c_compressor.pyx:13-186) over the segment call of the engine.
+    """``tamp.Compressor`` (tamp/_c_compressor.pyx:13-186) over the piece / segment calls of the engine.
 
-    ``write()`` gathers bytes; every ``flush()`` / ``reset_dictionary()`` / ``close()`` encodes what was gathered as
-    one SEGMENT on the GPU (``tamp_amd_compress_segment``), with the window carried from segment to segment in
-    ``_window`` / ``_window_pos`` exactly as ``TampCompressor.window`` / ``window_pos`` carry it.  The bytes that reach
-    ``f`` are the reference's; they reach it at flush points rather than during ``write()``, so ``write()`` returns 0.
+    ``write()`` gathers bytes and, whenever ``PIECE_MIN`` of them are waiting, hands them to the GPU as one PIECE
+    (``tamp_amd_compress_piece``, finish = 0): the piece ends as a ``tamp_compressor_compress`` call ends -- no FLUSH token,
+    no drain -- and the object keeps what the reference's object keeps (window, window position, a run / extended match
+    that is still growing, < 8 output bits, < 16 unparsed input bytes).  ``write()`` returns the bytes that reached ``f``
+    during the call, like the reference (tamp/_c_compressor.pyx:74-118), and memory stays bounded by ``PIECE_MAX``.
+    ``flush()`` / ``reset_dictionary()`` / ``close()`` end the segment on the GPU (FLUSH tokens, ``dictionary_reset``,
+    ``append`` are produced by the kernel, not emulated on the host).  With ``lazy_matching`` the cached match of
+    compressor.c:576-619 is not carried between pieces: such a stream is gathered until the next flush point.
     """
+
+    PIECE_MIN = 64 << 10  # bytes gathered before a piece is worth a launch
+    PIECE_MAX = 8 << 20   # most bytes handed over at once
 
     def __init__(self, f, *, window: int = 10, literal: int = 8, dictionary=None, lazy_matching: bool = False,
                  extended: bool = True, dictionary_reset: bool = False, append: bool = False, device: int = 0):
@@ -76,25 +83,78 @@ class Compressor:
         if dictionary is not None:
             self._window[:] = bytes(dictionary)
         self._window_pos = C.c_uint16(0)
+        self._carry = _lib.TampAmdCarry()
         self._pending = bytearray()
         self._opened = False    # header / append marker already sent
         self._resume = False    # _window holds a carried window (else: fresh stream)
+        self._dirty = False     # data was handed over since the last flush point (compressor.c:548)
         self._last_was_flush = self._append  # compressor.c:234
         self._device = device
+        self._streaming = not lazy_matching
         _lib.load()  # fail loudly now if the native library is missing
+
+    def _call(self, data: bytes, finish: bool, want_token: bool):
+        """One piece on the GPU; returns (bytes written to f, FLUSH token written)."""
+        lib = _lib.load()
+        n = len(data)
+        cap = lib.tamp_amd_compress_bound(n + 272, self._conf.literal, 0) + 8
+        out = (C.c_ubyte * cap)()
+        written = C.c_size_t(0)
+        token = C.c_int(0)
+        src = (C.c_ubyte * max(n, 1)).from_buffer_copy(data if n else b"\0")
+        first = not self._opened
+        res = lib.tamp_amd_compress_piece(
+            C.byref(self._conf), int(first and not self._append), int(first and self._append), int(self._resume),
+            int(finish), int(want_token), self._window, C.byref(self._window_pos), C.byref(self._carry), out, cap,
+            C.byref(written), src, n, C.byref(token), self._device)
+        if res < 0:
+            _raise_for(res)
+        if res == _lib.OUTPUT_FULL:
+            raise RuntimeError("tamp_amd: piece output did not fit its bound")  # (cannot happen: cap is the worst case)
+        self._opened = self._resume = True
+        if written.value:
+            self.f.write(bytes(out[: written.value]))
+        return written.value, bool(token.value)
 
     def write(self, data) -> int:
         self._pending += bytes(data)
-        return 0
+        if not self._streaming or len(self._pending) < self.PIECE_MIN:
+            return 0
+        total = 0
+        while len(self._pending) >= self.PIECE_MIN:  # bounded pieces, no flush token in between
+            piece = bytes(self._pending[: self.PIECE_MAX])
+            del self._pending[: len(piece)]
+            total += self._call(piece, finish=False, want_token=False)[0]
+            self._dirty = True
+        return total
 
     def _segment(self, flush_token: bool) -> int:
-        lib = _lib.load()
         n = len(self._pending)
-        if n:
+        if n or self._dirty:
             self._last_was_flush = False  # compressor.c:548
         want_token = bool(flush_token) and not self._last_was_flush  # compressor.c:784
-        if n == 0 and self._opened and not (want_token and self._dictionary_reset):
+        if n == 0 and not self._dirty and self._opened and not (want_token and self._dictionary_reset):
             return 0  # byte aligned, nothing buffered: the reference's flush writes nothing either
+        if self._streaming:
+            total = 0
+            while len(self._pending) > self.PIECE_MAX:  # (a flush after a very large gathered write: still bounded pieces)
+                piece = bytes(self._pending[: self.PIECE_MAX])
+                del self._pending[: len(piece)]
+                total += self._call(piece, finish=False, want_token=False)[0]
+            written, token = self._call(bytes(self._pending), finish=True, want_token=want_token)
+            total += written
+        else:
+            total, token = self._segment_gathered(want_token)
+        self._pending.clear()
+        self._dirty = False
+        if token:
+            self._last_was_flush = True
+        return total
+
+    def _segment_gathered(self, want_token: bool):
+        """lazy_matching: everything since the last flush point as ONE segment (tamp_amd_compress_segment)."""
+        lib = _lib.load()
+        n = len(self._pending)
         cap = lib.tamp_amd_compress_bound(n, self._conf.literal, 0) + 4
         out = (C.c_ubyte * cap)()
         written = C.c_size_t(0)
@@ -107,12 +167,9 @@ class Compressor:
         if res < 0:
             _raise_for(res)
         self._opened = self._resume = True
-        self._pending.clear()
-        if token.value:
-            self._last_was_flush = True
         if written.value:
             self.f.write(bytes(out[: written.value]))
-        return written.value
+        return written.value, bool(token.value)
 
     def flush(self, write_token: bool = True) -> int:
         n = self._segment(write_token)
@@ -128,6 +185,7 @@ class Compressor:
             self._last_was_flush = False
             total += self._segment(True)
         self._resume = False  # next segment starts from the seed dictionary again (never the custom one)
+        self._carry = _lib.TampAmdCarry()
         self._conf.use_custom_dictionary = 0
         self._window_pos = C.c_uint16(0)
         self._last_was_flush = self._append

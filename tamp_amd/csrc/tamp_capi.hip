@@ -1499,6 +1499,48 @@ tamp_res compat_segment(TampCompressor* compressor, unsigned char* output, size_
 }
 }  // namespace
 
+namespace {
+// tamp_compressor_compress on an object, large input, ample output room: ONE piece for the batch kernel
+// (tamp_amd_compress_piece, finish = 0) instead of token-by-token parsing by one wavefront -- the same stream and the
+// same object state as far as any later call can tell, except that every whole output byte leaves now (the reference
+// would hold the last token's bits back until the next poll: `written` may run up to four bytes ahead of it).
+constexpr size_t kCompatPieceMin = 64 << 10;
+bool compat_piece_applies(const TampAmdEncoderState* s, size_t input_size, size_t output_size) {
+    if (input_size < kCompatPieceMin || input_size > 0xFFFFFF00ull) return false;
+    if ((s->flags >> 4) & 1) return false;  // lazy matching: the cached match is not carried
+    if (s->cached_match_index >= 0 || s->input_size > 16 || s->bit_buffer_pos > 31) return false;
+    return output_size >= tamp_amd_compress_bound(input_size + 300, s->literal, 0) + 8;
+}
+
+tamp_res compat_piece(TampCompressor* compressor, unsigned char* output, size_t output_size, size_t* written,
+                      const unsigned char* input, size_t input_size) {
+    TampAmdEncoderState* s = enc_state(compressor);
+    TampAmdConf c;
+    std::memset(&c, 0, sizeof c);
+    c.window = s->window, c.literal = s->literal, c.extended = (s->flags >> 1) & 1;
+    c.use_custom_dictionary = s->flags & 1, c.dictionary_reset = (s->flags >> 2) & 1;
+    TampAmdCarry carry;
+    std::memset(&carry, 0, sizeof carry);
+    carry.rle_count = s->rle_count, carry.ext_count = s->extended_match_count, carry.ext_pos = s->extended_match_position;
+    carry.bit_count = s->bit_buffer_pos, carry.bits = s->bit_buffer;
+    carry.tail_len = s->input_size;
+    for (uint32_t k = 0; k < s->input_size; k++) carry.tail[k] = s->input[(s->input_pos + k) & 15];
+    uint16_t wp = s->window_pos;
+    int token = 0;
+    // (resume = 1: the object's window buffer IS the state -- seeded or custom at init, carried since)
+    tamp_res r = tamp_amd_compress_piece(&c, 0, 0, 1, 0, 0, compressor->window, &wp, &carry, output, output_size, written,
+                                         input, input_size, &token, compat_device());
+    if (r != TAMP_OK) return r;
+    s->window_pos = wp;
+    s->rle_count = carry.rle_count, s->extended_match_count = carry.ext_count, s->extended_match_position = carry.ext_pos;
+    s->bit_buffer_pos = carry.bit_count, s->bit_buffer = carry.bit_count ? carry.bits : 0u;
+    s->input_pos = 0, s->input_size = carry.tail_len;
+    for (uint32_t k = 0; k < 16; k++) s->input[k] = k < carry.tail_len ? carry.tail[k] : 0;
+    s->last_was_flush = 0;  // compressor.c:548
+    return TAMP_OK;
+}
+}  // namespace
+
 tamp_res tamp_compressor_init(TampCompressor* compressor, const TampConf* conf, unsigned char* window) {
     TampAmdConf c;
     std::memset(&c, 0, sizeof c);
@@ -1550,11 +1592,21 @@ tamp_res tamp_compressor_compress_cb(TampCompressor* compressor, unsigned char* 
     // callback (common.h:184-210: (input consumed, total input)) fires after every piece.
     size_t consumed = 0, written = 0;
     tamp_res r = TAMP_OK;
+    if (output_written_size) *output_written_size = 0;
+    if (input_consumed_size) *input_consumed_size = 0;
+    if (!enc_ready(enc_state(compressor)) || !compressor->window) return TAMP_ERROR;
+    // with a progress callback the pieces are smaller: it fires -- and may abort -- after each of them
+    const size_t piece_max = callback ? std::min<size_t>(kCompatPiece, env_or("TAMP_AMD_PROGRESS_PIECE_MB", 16) << 20) : kCompatPiece;
     do {
-        const size_t piece = std::min(input_size - consumed, kCompatPiece);
+        const size_t piece = std::min(input_size - consumed, piece_max);
         size_t c = 0, w = 0;
-        r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS, false, output + written, output_size - written, &w,
-                                input + consumed, piece, &c);
+        if (compat_piece_applies(enc_state(compressor), piece, output_size - written)) {
+            r = compat_piece(compressor, output + written, output_size - written, &w, input + consumed, piece);
+            if (r == TAMP_OK) c = piece;  // (every byte is taken: parsed, or waiting in the ring)
+        } else {
+            r = compat_encoder_call(compressor, TAMP_AMD_OP_COMPRESS, false, output + written, output_size - written, &w,
+                                    input + consumed, piece, &c);
+        }
         consumed += c, written += w;
         if (r == TAMP_OK && callback) {
             int cb = callback(user_data, consumed, input_size);
@@ -1872,20 +1924,27 @@ tamp_res tamp_decompressor_decompress(TampDecompressor* decompressor, unsigned c
 // Segment call: one piece of a stream between two flush points, with the window carried in and out.
 // This is what tamp.Compressor.write()/flush()/reset_dictionary() need (compressor.c:227-241,728-881).
 // ---------------------------------------------------------------------------------------------
-tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int append_marker, int resume,
-                                   int flush_token, unsigned char* window_state, uint16_t* window_pos,
-                                   unsigned char* output, size_t output_size, size_t* output_written_size,
-                                   const unsigned char* input, size_t input_size, int* token_written, int device) {
+namespace {
+// One piece of a stream on the batch kernel.  finish = 1: the piece ends with tamp_compressor_flush(flush_token) -- a
+// SEGMENT; finish = 0: it ends the way tamp_compressor_compress ends a call (compressor.c:681-722) and `carry` takes what
+// the reference's object would still hold.  A carry that comes in is continued from (its run / extended match bytes and
+// its unparsed tail are put back in front of the input: tamp_compress_kernel.hpp, kSegStateExtra).
+tamp_res segment_core(const TampAmdConf* conf, int emit_header, int append_marker, int resume, int finish, int flush_token,
+                      unsigned char* window_state, uint16_t* window_pos, TampAmdCarry* carry, unsigned char* output,
+                      size_t output_size, size_t* output_written_size, const unsigned char* input, size_t input_size,
+                      int* token_written, int device) {
     if (output_written_size) *output_written_size = 0;
     if (token_written) *token_written = 0;
     if (!conf_valid(conf) || conf->lazy_matching > 1 || !window_state || !window_pos) return TAMP_INVALID_CONF;
-    if (input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;
+    if (!finish && (!carry || conf->lazy_matching)) return TAMP_AMD_BAD_ARGUMENT;  // (lazy: the cached match is not carried)
+    if (input_size > 0xFFFFFF00ull) return TAMP_AMD_BAD_ARGUMENT;
     DeviceCtx* ctx = nullptr;
     int rc = get_ctx(device, &ctx);
     if (rc != TAMP_OK) return (tamp_res)rc;
     const size_t W = (size_t)1 << conf->window;
+    const size_t SS = W + kSegStateExtra;
     SegmentSpec seg;
-    seg.flags = kSegSave | (resume ? kSegResume : 0) | (flush_token ? kSegFlushToken : 0);
+    seg.flags = kSegSave | (resume ? kSegResume : 0) | ((finish && flush_token) ? kSegFlushToken : 0) | (finish ? 0 : kSegPartial);
     if (append_marker) {  // compressor.c:227-235: FLUSH (9 bits) padded to 16 bits instead of a header
         seg.nlead = 2, seg.lead = (uint16_t)(0xABu << 7);
     } else if (emit_header) {
@@ -1896,11 +1955,29 @@ tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int
     } else {
         seg.nlead = 0, seg.lead = 0;
     }
+    // what leads the input: the bytes a carried run / extended match has consumed (they are window bytes: the last byte
+    // written, resp. window[pos .. pos + count)), then the carried tail of the 16-byte ring
+    std::vector<unsigned char> prefix;
+    std::vector<unsigned char> stbuf(SS, 0);
+    std::memcpy(stbuf.data(), window_state, W);
+    stbuf[W] = (unsigned char)(*window_pos & 0xFF), stbuf[W + 1] = (unsigned char)(*window_pos >> 8);
+    if (carry && resume) {
+        if (carry->tail_len > 16 || carry->bit_count > 31 || (carry->rle_count && carry->ext_count) ||
+            (size_t)carry->ext_pos + carry->ext_count > W || ((emit_header || append_marker) && carry->bit_count))
+            return TAMP_AMD_BAD_ARGUMENT;
+        const unsigned char last = window_state[(*window_pos - 1) & (W - 1)];
+        prefix.insert(prefix.end(), carry->rle_count, last);
+        prefix.insert(prefix.end(), window_state + carry->ext_pos, window_state + carry->ext_pos + carry->ext_count);
+        prefix.insert(prefix.end(), carry->tail, carry->tail + carry->tail_len);
+        stbuf[W + 3] = carry->rle_count, stbuf[W + 4] = carry->ext_count, stbuf[W + 5] = carry->bit_count;
+        stbuf[W + 6] = (unsigned char)(carry->ext_pos & 0xFF), stbuf[W + 7] = (unsigned char)(carry->ext_pos >> 8);
+        for (int k = 0; k < 4; k++) stbuf[W + 16 + k] = (unsigned char)(carry->bits >> (8 * k));
+    }
     DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_state, d_dict;
     const uint64_t zero = 0;
-    const uint32_t ilen = (uint32_t)input_size;
+    const uint32_t ilen = (uint32_t)(prefix.size() + input_size);
     const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
-    HIP_OK(d_in.alloc(input_size + 64));
+    HIP_OK(d_in.alloc((size_t)ilen + 64));
     HIP_OK(d_out.alloc(output_size));
     HIP_OK(d_io.alloc(8));
     HIP_OK(d_il.alloc(4));
@@ -1908,17 +1985,16 @@ tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int
     HIP_OK(d_oc.alloc(4));
     HIP_OK(d_ol.alloc(4));
     HIP_OK(d_st.alloc(1));
-    HIP_OK(d_state.alloc(W + 4));
-    std::vector<unsigned char> stbuf(W + 4, 0);
-    std::memcpy(stbuf.data(), window_state, W);
-    stbuf[W] = (unsigned char)(*window_pos & 0xFF), stbuf[W + 1] = (unsigned char)(*window_pos >> 8);
+    HIP_OK(d_state.alloc(SS));
     hipStream_t st = nullptr;
-    if (input_size) HIP_OK(hipMemcpyAsync(d_in.p, input, input_size, hipMemcpyHostToDevice, st));
+    if (!prefix.empty()) HIP_OK(hipMemcpyAsync(d_in.p, prefix.data(), prefix.size(), hipMemcpyHostToDevice, st));
+    if (input_size)
+        HIP_OK(hipMemcpyAsync(d_in.as<uint8_t>() + prefix.size(), input, input_size, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_io.p, &zero, 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_il.p, &ilen, 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_oo.p, &zero, 8, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_oc.p, &ocap, 4, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_state.p, stbuf.data(), W + 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_state.p, stbuf.data(), SS, hipMemcpyHostToDevice, st));
     const uint8_t* dict = nullptr;
     if (!resume && conf->use_custom_dictionary) {  // a fresh stream with a custom dictionary: the state buffer holds it
         HIP_OK(d_dict.alloc(W));
@@ -1933,7 +2009,7 @@ tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int
     int8_t status = TAMP_ERROR;
     HIP_OK(hipMemcpyAsync(&olen, d_ol.p, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(&status, d_st.p, 1, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(stbuf.data(), d_state.p, W + 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(stbuf.data(), d_state.p, SS, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     if (olen) HIP_OK(hipMemcpy(output, d_out.p, olen, hipMemcpyDeviceToHost));
     if (output_written_size) *output_written_size = olen;
@@ -1941,8 +2017,46 @@ tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int
         std::memcpy(window_state, stbuf.data(), W);
         *window_pos = (uint16_t)(stbuf[W] | (stbuf[W + 1] << 8));
         if (token_written) *token_written = stbuf[W + 2];
+        if (carry) {
+            std::memset(carry, 0, sizeof *carry);
+            if (!finish) {
+                carry->rle_count = stbuf[W + 3], carry->ext_count = stbuf[W + 4], carry->bit_count = stbuf[W + 5];
+                carry->ext_pos = (uint16_t)(stbuf[W + 6] | (stbuf[W + 7] << 8));
+                carry->bits = (uint32_t)stbuf[W + 16] | ((uint32_t)stbuf[W + 17] << 8) | ((uint32_t)stbuf[W + 18] << 16) |
+                              ((uint32_t)stbuf[W + 19] << 24);
+                const uint32_t parsed = (uint32_t)stbuf[W + 9] | ((uint32_t)stbuf[W + 10] << 8) |
+                                        ((uint32_t)stbuf[W + 11] << 16) | ((uint32_t)stbuf[W + 12] << 24);
+                const uint32_t left = ilen - parsed;  // < 16: the ring never stays full (compressor.c:704-718)
+                if (parsed > ilen || left > 15) return TAMP_ERROR;
+                carry->tail_len = (uint8_t)left;
+                for (uint32_t j = 0; j < left; j++) {
+                    const size_t at = (size_t)parsed + j;
+                    carry->tail[j] = at < prefix.size() ? prefix[at] : input[at - prefix.size()];
+                }
+            }
+        }
+    } else if (!finish && status == TAMP_OUTPUT_FULL) {
+        return TAMP_OUTPUT_FULL;  // (the carry is left as it came in: give the piece tamp_amd_compress_bound(input_size + 271) of room)
     }
     return status;
+}
+}  // namespace
+
+tamp_res tamp_amd_compress_segment(const TampAmdConf* conf, int emit_header, int append_marker, int resume,
+                                   int flush_token, unsigned char* window_state, uint16_t* window_pos,
+                                   unsigned char* output, size_t output_size, size_t* output_written_size,
+                                   const unsigned char* input, size_t input_size, int* token_written, int device) {
+    return segment_core(conf, emit_header, append_marker, resume, 1, flush_token, window_state, window_pos, nullptr, output,
+                        output_size, output_written_size, input, input_size, token_written, device);
+}
+
+tamp_res tamp_amd_compress_piece(const TampAmdConf* conf, int emit_header, int append_marker, int resume, int finish,
+                                 int flush_token, unsigned char* window_state, uint16_t* window_pos, TampAmdCarry* carry,
+                                 unsigned char* output, size_t output_size, size_t* output_written_size,
+                                 const unsigned char* input, size_t input_size, int* token_written, int device) {
+    if (!carry) return TAMP_AMD_BAD_ARGUMENT;
+    return segment_core(conf, emit_header, append_marker, resume, finish, flush_token, window_state, window_pos, carry, output,
+                        output_size, output_written_size, input, input_size, token_written, device);
 }
 
 }  // extern "C"

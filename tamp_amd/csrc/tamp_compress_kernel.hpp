@@ -59,7 +59,7 @@ struct CompressArgs {
     uint8_t nlead;      // leading bytes 0..2: header (+ zero byte with dictionary_reset), FLUSH+pad when appending, none when resuming
     uint16_t lead;      // those bytes, first one in the high byte
     uint8_t seg_flags;  // kSegResume | kSegSave | kSegFlushToken
-    uint8_t* state;     // per stream: (1 << wbits) window bytes in ring order, then u16 window_pos, then u8 token-written flag
+    uint8_t* state;     // per stream: (1 << wbits) + kSegStateExtra bytes, see kSegStateExtra
     uint32_t* work_counter;    // TAMP_STREAM_LOOP builds: next stream index to hand out (zeroed before the launch)
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t cut_run;          // epoch cut: a run of this many aligned dwords of one byte ends the block (0 = off)
@@ -208,6 +208,7 @@ struct Walk {
     bool last_ext_direct = false;  // (instrumented builds)
     uint32_t dbg_lag_rle = 0, dbg_lag_ext = 0, dbg_lag_rle_short = 0;  // (instrumented builds)
     uint32_t ntok, ns;
+    bool partial = false;  // kSegPartial: every slow step is ONE poll with a full 16-byte ring (no whole-run / whole-match shortcuts)
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
     uint32_t lazy_idx, lazy_len;
@@ -366,7 +367,7 @@ struct Walk {
         const uint32_t sv = uni(blen[rd]);
         len = sv & 0x1Fu;
         idx = uni(bidx[rd]);
-        if constexpr (RB) ext_resolved = (sv & 0x40u) != 0;  // idx is the final index of the extended match that starts here
+        if constexpr (RB) ext_resolved = (sv & 0x40u) != 0 && !partial;  // idx is the final index of the extended match that starts here
         return true;
     }
 
@@ -531,7 +532,18 @@ struct Walk {
 #define TAMP_BRK_MIN 512
 #endif
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
-enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4 };
+enum : uint8_t { kSegResume = 1, kSegSave = 2, kSegFlushToken = 4, kSegPartial = 8 };
+// Per-stream state slot of the segment calls: the window in ring order, then
+//   [W] u16 window_pos   [W+2] u8 FLUSH token written (out)   [W+3] u8 rle_count   [W+4] u8 extended-match count
+//   [W+5] u8 pending output bits (in: 0..31, a reference object may sit on a whole token; out: 0..7)
+//   [W+6] u16 extended-match window position   [W+9] u32 input bytes parsed (out, unaligned)
+//   [W+16] u32 the pending bits, left aligned (first bit in bit 31; unaligned)
+// The fields behind the token flag are what a TampCompressor carries between two calls that are NOT separated by a
+// flush (compressor.h:13-66: rle_count, extended_match_count / _position, the bit buffer); kSegPartial ends the launch
+// the way tamp_compressor_compress_cb ends a call (compressor.c:681-722): parse steps only while 16 bytes of look-ahead
+// are there, no drain.  The bytes a pending run / extended match has consumed, and the unparsed tail of the previous
+// call, come back IN FRONT of the next call's input (the host shim puts them there).
+constexpr uint32_t kSegStateExtra = 24;
 // ctl words
 enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 5, cExcess = 6, cBlk = 7, cWave = 8, cNruns = 12, cQuad = 13, cNext = 14, cCut = 15, cCutThr = 16 };
 
@@ -639,7 +651,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         uint8_t* const gout = a.out + uni_u64(a.out_off[s]);
         const uint32_t cap = Walk::uni(a.out_cap[s]);
 
-        uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + 4) : nullptr;
+        uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + kSegStateExtra) : nullptr;
+        const bool partial = (a.seg_flags & kSegPartial) != 0;
         uint32_t wp0 = 0;
         if (st_io && (a.seg_flags & kSegResume)) {
             // window <- saved state (ring order) rotated so that the oldest byte comes first
@@ -652,23 +665,34 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         } else {
             for (uint32_t k = tid; k < W; k += nt) ebuf[k] = a.dict[k];
         }
-        // bit buffer: leading bytes (header, compressor.c:236-241; FLUSH + pad when appending, :227-235), rest zero
-        for (uint32_t k = tid; k < L.obuf_words; k += nt)
-            obuf[k] = k == 0 ? __builtin_bswap32((uint32_t)a.lead << 16) : 0;
+        // carried over from a call that ended without a flush (kSegStateExtra): pending run / extended match, pending bits
+        uint32_t c_rle = 0, c_ext = 0, c_extpos = 0, c_nbits = 0, c_bits = 0;
+        if (st_io && (a.seg_flags & kSegResume)) {
+            c_rle = Walk::uni(st_io[W + 3]), c_ext = Walk::uni(st_io[W + 4]), c_nbits = Walk::uni(st_io[W + 5]) & 31u;
+            c_extpos = Walk::uni((uint32_t)st_io[W + 6] | ((uint32_t)st_io[W + 7] << 8));
+            c_bits = Walk::uni((uint32_t)st_io[W + 16] | ((uint32_t)st_io[W + 17] << 8) | ((uint32_t)st_io[W + 18] << 16) |
+                               ((uint32_t)st_io[W + 19] << 24));
+        }
+        // bit buffer: leading bytes (header, compressor.c:236-241; FLUSH + pad when appending, :227-235) or the carried
+        // bits, rest zero
+        const uint32_t word0 = a.nlead ? (uint32_t)a.lead << 16 : (c_nbits ? c_bits & (0xFFFFFFFFu << (32 - c_nbits)) : 0u);
+        for (uint32_t k = tid; k < L.obuf_words; k += nt) obuf[k] = k == 0 ? __builtin_bswap32(word0) : 0;
 
         Walk wk;
         wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
         wk.wp_e = wp0, wk.wr = 0, wk.rd = 0, wk.nvalid = 0;
-        wk.rle_count = 0, wk.ext_count = 0, wk.ext_pos = 0, wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+        // (a carried run / extended match: its bytes lead the input and count as consumed, like a pending token after a re-base)
+        wk.rle_count = c_rle, wk.ext_count = c_ext, wk.ext_pos = c_extpos, wk.rd = c_rle + c_ext, wk.partial = partial;
+        wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         if (tid_k == 0) ctl[cCutThr] = a.cut_run;  // (read after the load phase's barrier)
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
 
         // workgroup-uniform output state
-        uint32_t carry = 8u * a.nlead;  // bits already sitting in obuf
+        uint32_t carry = a.nlead ? 8u * a.nlead : c_nbits;  // bits already sitting in obuf
         uint32_t gpos = 0;                         // bytes already flushed to HBM
-        uint32_t e_p0 = 0, e_pending = 0, e_wp = wp0;  // epoch parameters
+        uint32_t e_p0 = 0, e_pending = c_rle + c_ext, e_wp = wp0;  // epoch parameters
         bool need_match = true;
         // Positions matched per epoch.  A token that breaks the speculation throws the rest of the block away, so
         // after such a break the next block is small (data with long runs / window-end truncations tends to break
@@ -1093,6 +1117,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
                         slow = (prev == b0 && (b1 == b0 || R == 1)) || (!lazy && len > minp + 11);
                     }
+                    // kSegPartial: no parse step without a full ring -- the chain of plain steps stops where the call ends
+                    if (partial && leftq < kRing) slow = true;
                     blen[q] = (uint8_t)(len | (slow ? 0x80u : 0u) | (RUNS && sole_ext ? 0x40u : 0u));
                     bidx[q] = (uint16_t)(W - (key & 0xFFFFu));
                     TAMP_FINE(f2);
@@ -1223,6 +1249,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             if (!(sv & 0x80u)) continue;
                             const uint32_t len = sv & 0x1Fu;
                             const uint32_t leftq = n - (e_p0 + q);
+                            if (partial && leftq < kRing) continue;  // (the call ends in front of this position)
                             const uint32_t wpq = (e_wp + q) & mask;  // window_pos when the walk arrives here clean
                             const uint32_t b4 = lds_u32_unaligned(ebuf, W + q - 1);  // previous byte, then the next three
                             const uint32_t prev = b4 & 0xFFu, b0 = (b4 >> 8) & 0xFFu, b1 = (b4 >> 16) & 0xFFu;
@@ -1256,6 +1283,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             }
                             const uint32_t cnt = min(m, lim);
                             if (cnt >= t0 || cnt < len || wpq + cnt > W) continue;
+                            // (kSegPartial: the reference takes this match a 16-byte ring at a time; the poll that emits
+                            // the token must still have had a full ring)
+                            if (partial && leftq < cnt + kRing) continue;
                             blen[q] = (uint8_t)(0x20u | len);
                             xcnt[q] = (uint8_t)cnt;
                         }
@@ -1412,11 +1442,12 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         if (nhop) continue;
                     }
                     const uint32_t p = w_p0 + wk.rd;
-                    if (p < n) {
+                    if (partial ? n - p >= kRing : p < n) {
                         const uint32_t pending = wk.rle_count + wk.ext_count;
                         int r = Walk::kStepRebase;
                         if (wk.rd <= cur_blk + pending) {
-                            const uint32_t leftp = n - p;
+                            // (kSegPartial: exactly one poll -- the ring holds 16 bytes and nothing is known beyond it)
+                            const uint32_t leftp = partial ? kRing : n - p;
 #ifdef TAMP_PROF
                             const unsigned long long t0 = __builtin_readcyclecounter();
                             const uint32_t ec0 = wk.ext_count;
@@ -1440,7 +1471,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             act = kActDone;
                             break;
                         }
-                    } else if (ext && wk.rle_count >= 1) {  // compressor.c:748-763
+                    } else if (!partial && ext && wk.rle_count >= 1) {  // compressor.c:748-763
                         if (wk.rle_count == 1) {
                             const uint32_t c = wk.win((wk.wp() - 1) & mask);  // uniform (readfirstlane inside)
                             wk.put((1u << lbits) | c, lbits + 1u);
@@ -1449,7 +1480,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             wk.emit_rle(wk.rle_count);
                         }
                         wk.rle_count = 0;
-                    } else if (ext && wk.ext_count) {  // compressor.c:764-766
+                    } else if (!partial && ext && wk.ext_count) {  // compressor.c:764-766
                         wk.emit_ext();
                     } else {
                         if (st_io && (a.seg_flags & kSegSave)) {  // hand the window back in ring order
@@ -1457,6 +1488,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             if (lane == 0) {
                                 st_io[W] = (uint8_t)wk.wp();
                                 st_io[W + 1] = (uint8_t)(wk.wp() >> 8);
+                                // what stays pending when the call ends without a flush (zero after a drain)
+                                st_io[W + 3] = (uint8_t)wk.rle_count, st_io[W + 4] = (uint8_t)wk.ext_count;
+                                st_io[W + 6] = (uint8_t)wk.ext_pos, st_io[W + 7] = (uint8_t)(wk.ext_pos >> 8);
+                                for (uint32_t k = 0; k < 4; k++) st_io[W + 9 + k] = (uint8_t)(p >> (8 * k));
                             }
                         }
                         act = kActDone;
@@ -1631,9 +1666,17 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             // flush whole words (or, at the end, the zero-padded / truncated byte count) to HBM
             uint32_t nbytes;
             if (act == kActDone)
-                nbytes = excess ? (tot >> 3) : ((tot + 7) >> 3);  // compressor.c:629-631 / :799-807
+                nbytes = (excess || partial) ? (tot >> 3) : ((tot + 7) >> 3);  // compressor.c:629-631 / :799-807
             else
                 nbytes = (tot >> 5) << 2;
+            if (act == kActDone && st_io && (a.seg_flags & kSegSave) && tid == 0) {
+                // the bits of the last, incomplete byte stay with the stream (partial_flush writes whole bytes only,
+                // compressor.c:65-75); after a drain the byte was padded and written: nothing is carried
+                const uint32_t nb = (partial && !excess) ? (tot & 7u) : 0u;
+                st_io[W + 5] = (uint8_t)nb;
+                st_io[W + 16] = 0, st_io[W + 17] = 0, st_io[W + 18] = 0;
+                st_io[W + 19] = nb ? reinterpret_cast<const uint8_t*>(obuf)[tot >> 3] : 0;
+            }
             {   // HBM stores are whole aligned dwords whatever the slab's byte alignment: a few head bytes, then
                 // dwords funnel-shifted out of the bit buffer, then the tail bytes
                 const uint8_t* ob = reinterpret_cast<const uint8_t*>(obuf);

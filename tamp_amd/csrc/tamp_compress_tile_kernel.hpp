@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256, 6) tamp_compress_tile_kernel(CompressArgs
     const uint32_t n = TWalk<WB>::uni(a.in_len[s]);
     uint8_t* const gout = a.out + uni_u64(a.out_off[s]);
     const uint32_t cap = TWalk<WB>::uni(a.out_cap[s]);
-    uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + 4) : nullptr;
+    uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + kSegStateExtra) : nullptr;
     uint32_t wp0 = 0;
     if (st_io && (a.seg_flags & kSegResume)) {
         // history <- saved window (ring order) rotated so that the oldest byte comes first

@@ -203,3 +203,137 @@ def test_numpy_integer_capacities_and_workspace_reuse(ta, checker):
     assert bool((back.status == 2).all().item())
     host = ta.compress_batch(rows.reshape(-1), off, ln, out_cap=np.int64(cap), max_in_len=L)  # host path, integer capacity
     assert host.stream(5) == want.stream(5)
+
+
+def test_compressor_write_streams_like_the_reference_object(ta):
+    """tamp.Compressor.write() (tamp/_c_compressor.pyx:74-118): bytes leave during the call and the stream is the
+    reference object's, with every write handed over as a piece (PIECE_MIN = 1) -- runs and extended matches growing
+    across calls, pieces shorter than the 16-byte ring, both formats, FLUSH tokens in between; the counts returned are
+    the reference's up to the bits its object holds back until the next poll."""
+    import io
+
+    from oracle.checker import Ref
+    from tamp_amd import workloads as wl
+
+    if not Ref.available():
+        pytest.skip("oracle/_ref (the reference C built in place) is the only checker with object-level calls")
+    ref = Ref()
+    rng = np.random.default_rng(2024)
+    prose, py = wl.real_text("prose"), wl.real_text("python")
+    runs = (b"x" * 700 + b"header\n" + b" " * 300 + b"y" * 5 + b"-" * 77 + b"\n") * 6
+    sources = [prose[40_000:140_000], py[10_000:90_000], runs, bytes(3000) + prose[:5000] + bytes(600)]
+    old_min = ta.Compressor.PIECE_MIN
+    ta.Compressor.PIECE_MIN = 1
+    try:
+        for si, src in enumerate(sources):
+            for ext in (True, False):
+                for trial in range(3):
+                    ops, pos = [], 0
+                    while pos < len(src):
+                        k = int(rng.choice([1, 3, 15, 16, 17, 40, 300, 5000, 20000]))
+                        ops.append(("write", src[pos : pos + k]))
+                        pos += k
+                        if rng.random() < 0.08:
+                            ops.append(("flush", bool(rng.integers(0, 2))))
+                    ops.append(("close",))
+                    want_counts = []
+                    rc, want = ref.stream_script(ops, window=10, literal=8, extended=ext, counts=want_counts)
+                    assert rc == 0
+                    f = io.BytesIO()
+                    c = ta.Compressor(f, window=10, literal=8, extended=ext)
+                    got_counts = []
+                    for op in ops:
+                        if op[0] == "write":
+                            got_counts.append(c.write(op[1]))
+                        elif op[0] == "flush":
+                            got_counts.append(c.flush(op[1]))
+                        else:
+                            got_counts.append(c.close())
+                    assert f.getvalue() == want, (si, ext, trial)
+                    # The reference flushes whole bytes at the START of a poll (compressor.c:549-551), so its object sits on
+                    # the last token's bits (and on the header until the first poll) when a call returns; a piece hands every
+                    # whole byte over at once.  Same stream, up to four bytes earlier; equal again at every flush point.
+                    gc, wc = np.cumsum(got_counts), np.cumsum(want_counts)
+                    for k, op in enumerate(ops):
+                        if op[0] == "write":
+                            assert 0 <= gc[k] - wc[k] <= 4, (si, ext, trial, k, got_counts[k], want_counts[k])
+                        else:
+                            assert gc[k] == wc[k], (si, ext, trial, k)
+    finally:
+        ta.Compressor.PIECE_MIN = old_min
+    # the default thresholds: large writes leave in bounded pieces, small ones wait; the stream is the same
+    f = io.BytesIO()
+    with ta.Compressor(f) as c:
+        n1 = c.write(prose[:300_000])
+        n2 = c.write(prose[300_000:300_100])
+        assert n1 > 0 and n2 == 0
+    assert f.getvalue() == ta.compress(prose[:300_100])
+    assert bytes(ta.decompress(f.getvalue())) == prose[:300_100]
+
+
+def test_reference_named_object_takes_large_calls_as_pieces(ta, monkeypatch):
+    """tamp_compressor_compress[_cb] on a reference-named object (include/tamp_compat.h): calls of 64 KiB and more go to the
+    batch kernel as pieces, smaller ones to the token-level resume kernel -- mixed on ONE object the stream is still the
+    reference object's, and the progress callback (common.h:184-210) fires per piece and can abort."""
+    import ctypes as C
+
+    from oracle.checker import Ref
+    from tamp_amd import _lib
+    from tamp_amd import workloads as wl
+
+    if not Ref.available():
+        pytest.skip("needs oracle/_ref")
+    ref = Ref()
+    lib = _lib.load()
+
+    class TampConf(C.Structure):
+        _fields_ = [("window", C.c_uint16, 4), ("literal", C.c_uint16, 4), ("use_custom_dictionary", C.c_uint16, 1),
+                    ("extended", C.c_uint16, 1), ("dictionary_reset", C.c_uint16, 1), ("append", C.c_uint16, 1),
+                    ("lazy_matching", C.c_uint16, 1)]
+
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
+    sz = C.POINTER(C.c_size_t)
+    lib.tamp_compressor_init.restype = C.c_int8
+    lib.tamp_compressor_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tamp_compressor_compress_cb.restype = C.c_int8
+    lib.tamp_compressor_compress_cb.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_void_p, C.c_size_t, sz, CB, C.c_void_p]
+    lib.tamp_compressor_flush.restype = C.c_int8
+    lib.tamp_compressor_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, sz, C.c_bool]
+    no_cb = C.cast(None, CB)
+    data = wl.real_text("prose")[100_000:100_000 + 900_000] + b" " * 500 + wl.real_text("python")[:300_000]
+    sizes = [70_000, 5, 16, 200_000, 3, 100, 131_072, 15, 65_536, 1, 400_000]
+    for ext in (1, 0):
+        conf = TampConf(window=10, literal=8, extended=ext)
+        window, comp = (C.c_ubyte * 1024)(), (C.c_ubyte * 48)()
+        assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+        got, pos, ops = bytearray(), 0, []
+        for k in sizes + [len(data)]:
+            piece = data[pos : pos + k]
+            pos += len(piece)
+            if not piece:
+                break
+            ops.append(("write", piece))
+            out = (C.c_ubyte * (len(piece) * 2 + 4096))()
+            buf = (C.c_ubyte * len(piece)).from_buffer_copy(piece)
+            w, c = C.c_size_t(0), C.c_size_t(0)
+            assert lib.tamp_compressor_compress_cb(comp, out, len(out), C.byref(w), buf, len(piece), C.byref(c), no_cb, None) == 0
+            assert c.value == len(piece)
+            got += bytes(out[: w.value])
+        out, w = (C.c_ubyte * 64)(), C.c_size_t(0)
+        assert lib.tamp_compressor_flush(comp, out, 64, C.byref(w), False) == 0
+        got += bytes(out[: w.value])
+        rc, want = ref.stream_script(ops + [("flush", False)], window=10, literal=8, extended=bool(ext))
+        assert rc == 0 and bytes(got) == want, ext
+    # progress per piece, abort with a custom code
+    monkeypatch.setenv("TAMP_AMD_PROGRESS_PIECE_MB", "1")
+    conf = TampConf(window=10, literal=8, extended=1)
+    window, comp = (C.c_ubyte * 1024)(), (C.c_ubyte * 48)()
+    assert lib.tamp_compressor_init(comp, C.byref(conf), window) == 0
+    seen = []
+    cb = CB(lambda user, done, total: (seen.append((done, total)), 0 if done < (2 << 20) else 105)[1])
+    big = data[: (3 << 20) // 2 * 2][: 3 << 20] if len(data) >= (3 << 20) else (data * 3)[: 3 << 20]
+    buf = (C.c_ubyte * len(big)).from_buffer_copy(big)
+    out = (C.c_ubyte * (len(big) * 2))()
+    w, c = C.c_size_t(0), C.c_size_t(0)
+    assert lib.tamp_compressor_compress_cb(comp, out, len(out), C.byref(w), buf, len(big), C.byref(c), cb, None) == 105
+    assert seen == [(1 << 20, 3 << 20), (2 << 20, 3 << 20)] and c.value == 2 << 20
