@@ -268,13 +268,17 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     // streams of 1 KiB and more -- it settles short RLE runs and most extended matches in the match phase and is the faster
     // one on every kind of text measured, runs or not (config 2: 6.89 against 7.29 ms) -- the lean build for short
     // messages (256-byte telemetry: 2.2 against 2.5 ms), where its per-epoch run search does not pay
-    bool runlist = conf->input_hint == TAMP_AMD_HINT_RUNS || (conf->input_hint == TAMP_AMD_HINT_AUTO && (max_in_len == 0 || max_in_len >= 1024));
-    if (const char* e = getenv("TAMP_AMD_RUNS")) runlist = atoi(e) != 0;  // tuning / tests
-    runlist = runlist && !a.lazy;
+    // Round 3: six builds instead of nine.  Streams of 1 KiB and more (256-thread workgroups) always take the run-aware
+    // build -- it was the faster one on every kind of text in both formats, so the lean 256-thread builds only served the
+    // PLAIN hint; the hint now matters for short messages alone, where the lean one-wavefront build is ahead.  The 2^15
+    // window (u16 index entries) has the lean and the lazy build only.
+    const bool long_streams = max_in_len == 0 || align_up(max_in_len, 64) >= 1024;  // (= 256-thread workgroups, pick_block)
+    bool runlist = packed && !a.lazy && (long_streams || conf->input_hint == TAMP_AMD_HINT_RUNS);
+    if (const char* e = getenv("TAMP_AMD_RUNS")) { if (!long_streams) runlist = packed && !a.lazy && atoi(e) != 0; }  // tuning / tests
     a.blk = pick_block(W, max_in_len, packed, a.lazy != 0, runlist);
-    if (runlist && CompressLds(W, a.blk, packed, false, true).total > ctx->lds_per_block) {  // largest windows: no room
-        runlist = false;
-        a.blk = pick_block(W, max_in_len, packed, false, false);
+    if (runlist && CompressLds(W, a.blk, packed, false, true).total > ctx->lds_per_block) {
+        snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", CompressLds(W, a.blk, packed, false, true).total, ctx->lds_per_block);
+        return TAMP_AMD_BAD_ARGUMENT;  // (cannot happen for windows up to 2^14: 105 KB at most)
     }
     const CompressLds L(W, a.blk, packed, a.lazy != 0, runlist);
     if (L.total > ctx->lds_per_block) {
@@ -309,14 +313,17 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
             return TAMP_OK;
         }
     }
+    // the six builds: lazy (u32 / u16 entries), run-aware (generic window / 2^10 with the scan constants as immediates),
+    // lean one-wavefront build for short messages (512 buckets: a quarter of the cursors to zero and scan per message),
+    // lean u16 build for the 2^15 window
     auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true> : tamp_compress_kernel<false, true>)
-                  : runlist ? (packed ? tamp_compress_kernel<true, false, true> : tamp_compress_kernel<false, false, true>)
-                            : (packed ? tamp_compress_kernel<true, false> : tamp_compress_kernel<false, false>);
-    if (conf->window == 10 && packed && !a.lazy && !getenv("TAMP_AMD_NOWSCAN"))  // bucket-scan constants as immediates
-        kernel = runlist ? tamp_compress_kernel<true, false, true, 1024> : tamp_compress_kernel<true, false, false, 1024>;
-    // short blocks (one wavefront per stream): 512 buckets -- a quarter of the cursors to zero and scan per message
-    // (256-byte telemetry 39.4 -> 40.2 GB/s; 1,024 buckets the same)
-    if (threads == 64 && packed && !a.lazy && !runlist && !getenv("TAMP_AMD_NOSHORT")) kernel = tamp_compress_kernel<true, false, false, 0, 9>;
+                  : !packed ? tamp_compress_kernel<false, false>
+                  : runlist ? (conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024> : tamp_compress_kernel<true, false, true>)
+                            : tamp_compress_kernel<true, false, false, 0, 9>;
+    if (packed && !a.lazy && !runlist && threads != 64) {  // (short messages only: long streams are run-aware above)
+        snprintf(t_last_error, sizeof t_last_error, "no lean build for %u-thread workgroups", threads);
+        return TAMP_AMD_BAD_ARGUMENT;
+    }
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
     g_last_encoder.store("epoch");
@@ -450,9 +457,10 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         size_t slice = std::min<size_t>(n_streams, (size_t)1 << slice_log2);
         const size_t per = (size_t)sa.tokcap * 4 + 4 + kSplitMaxLag * 8;
         {
-            // scratch budget: a quarter of what the device has free right now, 4 GiB at most (callers that fill HBM with
-            // their own batches keep most of it); TAMP_AMD_SPLIT_SCRATCH_MB overrides
-            size_t budget = (size_t)4 << 30, free_b = 0, total_b = 0;
+            // scratch budget: a quarter of what the device has free right now, 8 GiB at most (callers that fill HBM with
+            // their own batches keep most of it; a slice of 2^18 long streams needs ~3.7 GiB, and configs[3] cut into
+            // uneven slices by a 4 GiB budget ran 6.5 instead of 5.1 ms); TAMP_AMD_SPLIT_SCRATCH_MB overrides
+            size_t budget = (size_t)8 << 30, free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 4);
             else (void)hipGetLastError();
             if (const char* e = getenv("TAMP_AMD_SPLIT_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
