@@ -318,7 +318,7 @@ def pmc_traffic_bytes():
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "tamp_compress" in r["Kernel_Name"]]
         return sum(vals) / len(vals)
 
-    for tag in (PROFILE_TAG, "r1j"):
+    for tag in (PROFILE_TAG, "r2", "r1j"):
         try:
             fetch_kb = mean_kb(f"{tag}_pmc_fetch_counter_collection.csv")
             write_kb = mean_kb(f"{tag}_pmc_write_counter_collection.csv")
@@ -439,11 +439,35 @@ def also_v1_and_decode(shard, res, torch):
     gbs = (comp_bytes + shard.in_bytes) / (best * 1e-3) / 1e9
     out["decompress_output_MBps"] = round(shard.in_bytes / (best * 1e-3) / 1e6, 1)
     out["decompress_round_trip"] = "bit-exact" if ok else "MISMATCH"
+    traffic, tsrc = pmc_decode_traffic_bytes()
     out["decompress"] = {"kernel_ms": round(best, 4), "roofline": {
         "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
         "algorithmic_bytes_per_launch": comp_bytes + shard.in_bytes,
+        "traffic": traffic if (n == 65536 and shard.max_len == 4096) else None, "traffic_source": tsrc,
         "note": "compressed bytes read + bytes written, hipEvents around the decode launch (header pre-pass included)"}}
     return out
+
+
+def pmc_decode_traffic_bytes():
+    """HBM bytes of one decode of the bench batch (header pre-pass + parse + resolve + leftovers), from the committed
+    FETCH_SIZE / WRITE_SIZE passes over tools/dec_traffic.py (the bench's decode leg alone)."""
+    import csv
+
+    def total_kb(name):
+        per = {}
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+            k = r["Kernel_Name"]
+            if "tamp_" in k and "compress_kernel" not in k:
+                per.setdefault(k, []).append(float(r["Counter_Value"]))
+        return sum(sum(v) / len(v) for v in per.values())
+
+    try:
+        f = total_kb(f"{PROFILE_TAG}_pmc_dec2_fetch_counter_collection.csv")
+        w = total_kb(f"{PROFILE_TAG}_pmc_dec2_write_counter_collection.csv")
+    except Exception:
+        return None, "no committed PMC pass for the decode"
+    return int(2 * f * 1024 + w * 1024), (f"profiles/{PROFILE_TAG}_pmc_dec2_{{fetch,write}}_counter_collection.csv: 2 x FETCH_SIZE KB + "
+                                          "WRITE_SIZE KB summed over the decode's kernels (tools/dec_traffic.py, tools/pmc_run.sh)")
 
 
 def also_real_text(args, torch, np):

@@ -47,9 +47,11 @@ typedef struct TampAmdConf {
     uint8_t extended;              /* library default of the reference is 1 (compressor.c:193-203) */
     uint8_t dictionary_reset;      /* sets header bit0 and emits the zero second header byte */
     uint8_t lazy_matching;         /* compressor.c:576-619; a bit over half the default mode's speed */
-    uint8_t input_hint;            /* TAMP_AMD_HINT_*: which build of the compress kernel parses the batch (same bytes
-                                      either way).  AUTO goes by stream length alone: RUNS when max_in_len (given, or
-                                      computed from in_len for host memory) is 0 or >= 1024, else PLAIN. */
+    uint8_t input_hint;            /* TAMP_AMD_HINT_*: which build of the compress kernel parses a batch of SHORT messages
+                                      (same bytes either way).  Streams of 1 KiB and more -- max_in_len given, or computed
+                                      from in_len for host memory, 0 = unknown -- always take the run-aware build (round 3:
+                                      it was the faster one on every kind of text, so the lean 256-thread builds are gone);
+                                      shorter ones take the lean one-wavefront build unless the hint says RUNS. */
     uint8_t reserved;
 } TampAmdConf;
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 evidence, round 2.  Separate passes: kernel-trace/stats alone; each --pmc group alone (FETCH_SIZE and WRITE_SIZE
+# rocprofv3 evidence (rounds 2-3).  Separate passes: kernel-trace/stats alone; each --pmc group alone (FETCH_SIZE and WRITE_SIZE
 # do not fit into one pass).  Summaries land in gpurun_out/pmc_$TAG; copy what is to be tracked into profiles/.
 #   usage (GPU box, repo root): TAG=r2a bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r2a}
+TAG=${TAG:-r3a}
 OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 # ---- compress kernel (configs[1], the bench command) ----
@@ -29,6 +29,15 @@ python tools/short_msgs.py 1048576 > $OUT/short_msgs.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec2_stats -- python tools/dec_bench.py > $OUT/dec2_stats.log 2>&1
 # ---- real text, both formats ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o realtext_stats -- python tools/realtext.py > $OUT/realtext_stats.log 2>&1
+# ---- real text (frozen corpora, extended format) and configs[4] messages: instruction counters (round 3) ----
+SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+for c in prose python; do
+  CORPUS=$c EXT=1 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT -o realtext_${c}_sq -- python tools/one_corpus.py 32768 > $OUT/realtext_${c}_sq.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT -o c5_sq -- python tools/config5.py > $OUT/c5_sq.log 2>&1
+# ---- decode of the bench batch (65,536 x 4 KiB, split decoder): HBM traffic ----
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o dec2_fetch -- python tools/dec_traffic.py > $OUT/dec2_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o dec2_write -- python tools/dec_traffic.py > $OUT/dec2_write.log 2>&1
 ls $OUT
 cat $OUT/bench.json
 python - <<PY
