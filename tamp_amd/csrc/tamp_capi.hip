@@ -294,7 +294,8 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
         // (profiles/ab/README.md: 72 k against 53.6 k VALU instructions per 4 KiB stream, eight latency-bound builds).
         bool tile = false;
         if (const char* e = getenv("TAMP_AMD_ENCODER")) {
-            if (!strcmp(e, "tile")) tile = conf->window <= 10 && !a.lazy;
+            // (whole streams only: the tile kernel knows neither launches that end without a flush nor carried state)
+            if (!strcmp(e, "tile")) tile = conf->window <= 10 && !a.lazy && !seg;
         }
         if (tile) {
             const TileLds TL;
