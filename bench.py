@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--extended", type=int, default=1)
     ap.add_argument("--corpus", default=os.environ.get("TAMP_CORPUS"), help="file to cut into 4 KiB streams (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="timed loop only (profiling runs)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="take roofline.traffic / valu_* from the committed passes instead of profiling a short run now")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="streams timed on the host cores")
     args = ap.parse_args()
 
@@ -271,7 +273,15 @@ def main():
         result["roofline"]["traffic_source"] = src
         # the real limiter (SURVEY.md 8d's secondary counters): the kernel is bound by VALU issue, not by HBM
         result["roofline"].update(pmc_issue_figures(args.streams, sh0.in_bytes))
+        if rank == 0 and world == 1 and not args.no_live_pmc and not args.no_cpu_baseline:
+            # ... and measured now: three short rocprofv3 --pmc passes over this very command (own processes, separate
+            # passes as the guide prescribes); the committed figures above stay as the fallback and as a cross-check
+            live = live_pmc(args, sh0.in_bytes)
+            if live.get("traffic"):
+                result["roofline"]["traffic_committed"] = traffic
+                result["roofline"].update(live)
 
+    sh0.no_live_pmc = args.no_live_pmc
     extras = rank == 0 and not args.no_cpu_baseline
     if extras and world == 1:
         result["cpu_baseline"] = cpu_baseline(args, sh0, res[0], np, corpus_blob is not None)
@@ -329,6 +339,60 @@ def pmc_traffic_bytes():
             "passes, tools/pmc_run.sh) of this command; bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction) + "
             "WRITE_SIZE KB" + ("" if tag == PROFILE_TAG else " [STALE: captured on an earlier build of the kernel]"))
     return None, "no committed PMC pass"
+
+
+def live_pmc(args, in_bytes):
+    """HBM bytes and VALU figures of the compress kernel from rocprofv3 --pmc passes run NOW over `bench.py --steps 2
+    --warmup 1 --no-cpu-baseline --no-live-pmc` (FETCH_SIZE, WRITE_SIZE and the SQ group each in a pass of their own, with
+    --kernel-trace only); {} if rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc",
+           "--streams", str(args.streams), "--stream-len", str(args.stream_len), "--window", str(args.window),
+           "--extended", str(args.extended)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    t0 = time.perf_counter()
+    for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                          ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
+        d = tempfile.mkdtemp(prefix="tamp_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--", *cmd],
+                           cwd="/tmp", env=env, capture_output=True, timeout=240, check=True)
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "tamp_compress" in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for k, v in acc.items():
+                got[k] = sum(v) / len(v)
+        except Exception:
+            return {}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")
+    if any(k not in got for k in need):
+        return {}
+    cycles = got["GRBM_GUI_ACTIVE"] / 8.0
+    return {
+        "traffic": int(2 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024),
+        "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ group, one pass each, over "
+                          "`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc`; bytes per launch = 2 x FETCH_SIZE KB "
+                          "(gfx950 correction) + WRITE_SIZE KB",
+        "valu_per_stream": round(got["SQ_INSTS_VALU"] / args.streams),
+        "salu_per_stream": round(got.get("SQ_INSTS_SALU", 0) / args.streams),
+        "valu_busy": round(got["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 3),
+        "issue_ceiling_GBps": round(in_bytes / (got["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9)) / 1e9, 1),
+        "issue_source": "measured in this run (SQ pass above)",
+        "live_pmc_seconds": round(time.perf_counter() - t0, 1),
+    }
 
 
 def pmc_issue_figures(n_streams, in_bytes):
@@ -440,12 +504,53 @@ def also_v1_and_decode(shard, res, torch):
     out["decompress_output_MBps"] = round(shard.in_bytes / (best * 1e-3) / 1e6, 1)
     out["decompress_round_trip"] = "bit-exact" if ok else "MISMATCH"
     traffic, tsrc = pmc_decode_traffic_bytes()
+    if n == 65536 and shard.max_len == 4096 and not getattr(shard, "no_live_pmc", False):
+        live, lsrc = live_decode_traffic()
+        if live:
+            traffic, tsrc = live, lsrc
     out["decompress"] = {"kernel_ms": round(best, 4), "roofline": {
         "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
         "algorithmic_bytes_per_launch": comp_bytes + shard.in_bytes,
         "traffic": traffic if (n == 65536 and shard.max_len == 4096) else None, "traffic_source": tsrc,
         "note": "compressed bytes read + bytes written, hipEvents around the decode launch (header pre-pass included)"}}
     return out
+
+
+def live_decode_traffic():
+    """HBM bytes of one decode of the bench batch measured NOW: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (a pass each) over
+    tools/dec_traffic.py, summed over the decode's kernels; (None, why) if the profiler is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    script = os.path.join(ROOT, "tools", "dec_traffic.py")
+    if not os.path.exists(exe) or not os.path.exists(script):
+        return None, "no rocprofv3"
+    total_kb = {}
+    for tag in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tamp_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", tag, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, script],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", GRAFT_REPO_ROOT=ROOT), capture_output=True, timeout=240, check=True)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r["Kernel_Name"]
+                    if "tamp_" in k and "compress_kernel" not in k:
+                        per.setdefault(k, []).append(float(r["Counter_Value"]))
+            total_kb[tag] = sum(sum(v) / len(v) for v in per.values())
+        except Exception as e:  # noqa: BLE001
+            return None, repr(e)[:80]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if not total_kb.get("FETCH_SIZE") or not total_kb.get("WRITE_SIZE"):
+        return None, "no counter rows"
+    return int(2 * total_kb["FETCH_SIZE"] * 1024 + total_kb["WRITE_SIZE"] * 1024), (
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (a pass each) over tools/dec_traffic.py, "
+        "2 x FETCH_SIZE KB + WRITE_SIZE KB summed over the decode's kernels")
 
 
 def pmc_decode_traffic_bytes():
