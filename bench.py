@@ -577,14 +577,14 @@ def pmc_decode_traffic_bytes():
 
 def also_real_text(args, torch, np):
     """Real text (the frozen fixtures of tests/golden/make_corpus.py; the metric's own corpus, enwik8, is not in the
-    image): GB/s of input per corpus, both formats, 16,384 x 4 KiB streams (the corpus repeated to fill them), with the
-    first 512 streams of each checked against the reference C."""
+    image): GB/s of input per corpus, both formats, as many 4 KiB streams as the headline batch has (65,536; the 768
+    chunks of a corpus repeated to fill them), with the first 512 streams of each checked against the reference C."""
     import tamp_amd
     from tamp_amd import workloads as wl
 
     kind, impl = _checker()
     dev = torch.device("cuda", 0)
-    n, L = 16384, 4096
+    n, L = args.streams, 4096  # the headline's batch size (round 2 used 16,384: a quarter as many device fills, ~7 % slower per stream)
     out = {"streams": n, "stream_len": L, "checker": kind}
     sources = {name: wl.real_text(name) for name in wl.REAL_TEXT_SOURCES}
     sources["synthetic (configs[1] text)"] = None
