@@ -337,3 +337,58 @@ def test_reference_named_object_takes_large_calls_as_pieces(ta, monkeypatch):
     w, c = C.c_size_t(0), C.c_size_t(0)
     assert lib.tamp_compressor_compress_cb(comp, out, len(out), C.byref(w), buf, len(big), C.byref(c), cb, None) == 105
     assert seen == [(1 << 20, 3 << 20), (2 << 20, 3 << 20)] and c.value == 2 << 20
+
+
+def test_pieces_with_custom_dictionary_append_and_excess_bits(ta):
+    """Pieces in the corners of the streaming surface: a custom dictionary (the first piece starts from it, later ones from
+    the carried window), `append=True` (FLUSH marker instead of a header), 7-bit literals with an offending byte in a later
+    piece (ExcessBitsError as in the reference's write), windows 2^8 and 2^12."""
+    import io
+
+    from oracle.checker import Ref
+    from tamp_amd import workloads as wl
+
+    if not Ref.available():
+        pytest.skip("needs oracle/_ref")
+    ref = Ref()
+    rng = np.random.default_rng(77)
+    text = wl.real_text("python")[500_000:560_000]
+    old_min = ta.Compressor.PIECE_MIN
+    ta.Compressor.PIECE_MIN = 1
+    try:
+        for kw in (dict(window=8, dictionary=bytes(rng.integers(32, 127, 256, dtype=np.uint8))),
+                   dict(window=12, dictionary=(text[:3000] + bytes(4096))[:4096]),
+                   dict(window=10, dictionary_reset=True, append=True),
+                   dict(window=9, extended=False)):
+            ops, pos = [], 0
+            while pos < len(text):
+                k = int(rng.choice([5, 16, 33, 700, 9000]))
+                ops.append(("write", text[pos : pos + k]))
+                pos += k
+                if rng.random() < 0.1:
+                    ops.append(("flush", True))
+            ops.append(("close",))
+            rc, want = ref.stream_script(ops, literal=8, **{"lazy_matching": False, **kw})
+            assert rc == 0
+            f = io.BytesIO()
+            c = ta.Compressor(f, literal=8, **kw)
+            for op in ops:
+                if op[0] == "write":
+                    c.write(op[1])
+                elif op[0] == "flush":
+                    c.flush(op[1])
+                else:
+                    c.close()
+            assert f.getvalue() == want, kw
+        # literal=7: the byte 0xE9 sits in the third piece
+        seven = bytes(b & 0x7F for b in text[:6000])
+        bad = seven[:4000] + b"\xe9" + seven[4001:]
+        f = io.BytesIO()
+        c = ta.Compressor(f, literal=7)
+        c.write(bad[:1500])
+        c.write(bad[1500:3000])
+        with pytest.raises(ta.ExcessBitsError):
+            c.write(bad[3000:])
+            c.flush()
+    finally:
+        ta.Compressor.PIECE_MIN = old_min
