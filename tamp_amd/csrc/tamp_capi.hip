@@ -1098,12 +1098,18 @@ long long tamp_amd_trim(int device) {
     int rc = get_ctx(device, &ctx);
     if (rc != TAMP_OK) return rc;
     long long freed = 0;
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (auto& kv : ctx->slabs) {
-        DeviceCtx::Slab& slab = kv.second;
+    // lock order of the decode launches: a slab's launch_mu first, g_mu inside it -- so the slabs are listed under g_mu
+    // (map nodes do not move) and released one by one in that order
+    std::vector<std::pair<hipStream_t, DeviceCtx::Slab*>> slabs;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (auto& kv : ctx->slabs) slabs.emplace_back(kv.first, &kv.second);
+    }
+    for (auto& ps : slabs) {
+        DeviceCtx::Slab& slab = *ps.second;
         std::lock_guard<std::mutex> call_lock(slab.launch_mu);
-        if (!slab.p && !slab.split) continue;
-        if (hipStreamSynchronize(kv.first) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamSynchronize(ps.first) != hipSuccess) (void)hipGetLastError();
+        std::lock_guard<std::mutex> lock(g_mu);
         if (slab.p) { (void)hipFree(slab.p); freed += (long long)slab.bytes; slab.p = nullptr, slab.bytes = 0; }
         if (slab.split) { (void)hipFree(slab.split); freed += (long long)slab.split_bytes; slab.split = nullptr, slab.split_bytes = 0; }
     }
