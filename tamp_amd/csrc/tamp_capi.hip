@@ -1751,7 +1751,7 @@ tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, v
             int cb = callback(user_data, total_in, 0);
             if (cb) return (tamp_res)cb;
         }
-        out.resize(tamp_amd_compress_bound(in.size(), s->literal, 1) + 24);
+        out.resize(tamp_amd_compress_bound(in.size() + 320, s->literal, 1) + 64);  // (room that lets a buffer go as ONE piece)
         size_t written = 0, consumed = 0;
         if (eof) {  // last (or only) buffer: compress + flush
             tamp_res r = first ? tamp_compressor_compress_and_flush_cb(compressor, out.data(), out.size(), &written, in.data(),
