@@ -392,3 +392,29 @@ def test_pieces_with_custom_dictionary_append_and_excess_bits(ta):
             c.flush()
     finally:
         ta.Compressor.PIECE_MIN = old_min
+
+
+def test_bench_line_keeps_the_contract():
+    """The driver's contract for bench.py (one JSON line): every field it reads, the roofline and cpu_baseline objects, the
+    live counter passes, the real-text rates next to the headline."""
+    line = _bench(["--steps", "3", "--warmup", "1", "--cpu-sample", "2048"], {})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["unit"] == "MB/s" and line["dtype"] == "u8" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert line["scaling"] == "weak" and "configs[1]" in line["config"]["workload"] and "model" not in line["config"]
+    assert abs(line["value"] - 65536 * 4096 / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert roof["kernel_ms"] <= line["ms_per_step"] * 1.02
+    # traffic: measured in the run (or the committed pass): between 1 x and 1.5 x the algorithmic bytes
+    assert roof["algorithmic_bytes_per_launch"] <= roof["traffic"] <= 1.5 * roof["algorithmic_bytes_per_launch"], roof
+    assert 30_000 < roof["valu_per_stream"] < 80_000 and 0.5 < roof["valu_busy"] <= 1.0
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["unit"] == "MB/s" and cpu["value"] > 0
+    assert cpu["parity"].startswith("bit-exact"), cpu
+    rt = line["config"]["real_text_MBps"]
+    assert rt["prose"] > 1000 and rt["python"] > 1000
+    assert line["also"]["decompress_round_trip"] == "bit-exact"
