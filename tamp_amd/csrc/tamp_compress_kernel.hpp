@@ -980,7 +980,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                                 if (d <= Ws - 2 && (x & ((1u << kRem) - 1)) == 0) {
                                     const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
                                     uint32_t len = (x & (0xFFu << kRem)) ? 2u : 3u;
+#ifdef TAMP_PROF
+                                    // (0x8000: instruction-count experiment -- the loop without its 16-byte compares, i.e.
+                                    // what any scheme that takes the deep compares elsewhere leaves behind; results are wrong)
+                                    if ((x >> kRem) == 0 && !(a.dbg & 0x8000u)) len = prefix_len16(ebuf, c, P);
+                                    else if ((x >> kRem) == 0) len = 4u;
+#else
                                     if ((x >> kRem) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
+#endif
                                     // The candidate's first t bytes lie in front of the newest window byte, where the
                                     // buffer IS the ring: a common prefix shorter than t is exact whatever follows.  Only
                                     // a candidate that agrees all the way to the newest byte (periodic input: rare) goes
