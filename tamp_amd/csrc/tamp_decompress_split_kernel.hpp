@@ -34,11 +34,9 @@ namespace tamp_amd {
 
 constexpr uint32_t kSplitMaxLag = 48;      // lagging tokens listed per stream (more: the stream is left to the lane decoders)
 constexpr uint32_t kSplitMaxOut = 16384;   // bytes of output RESOLVE keeps in LDS (out_cap above: not a split-decoder batch)
-constexpr uint32_t kSplitRecLds = 1536;    // records RESOLVE copies into LDS (streams with more keep reading them from HBM / L2)
 __host__ __device__ constexpr uint32_t split_resolve_lds(uint32_t maxcap) {
-    // bytes + 16, one u16 pointer per byte, lag list, control words, the stream's records (while that keeps eight
-    // workgroups on a CU: out_cap up to 4 KiB + slack)
-    return ((maxcap + 15u) & ~15u) * 3u + 16u + kSplitMaxLag * 8u + 64u + (maxcap <= 4224u ? kSplitRecLds * 4u : 0u);
+    // bytes + 16, one u16 pointer per byte, lag list, control words
+    return ((maxcap + 15u) & ~15u) * 3u + 16u + kSplitMaxLag * 8u + 64u;
 }
 
 // record = kind | out_len << 2 | arg << 10;  arg = literal byte, or the window offset of a copy
@@ -433,7 +431,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     const uint32_t ntok = meta & 0xFFFFFu, wbits = 8 + ((meta >> 20) & 7), dict_sel = (meta >> 23) & 3, nlag = (meta >> 25) & 63;
     const uint32_t W = 1u << wbits, mask = W - 1;
     const uint8_t* const dict = dict_sel == 3 ? a.dict : a.seed_dicts + ((size_t)dict_sel << 15);
-    const uint32_t* rec = sa.recs + (size_t)k * sa.tokcap;
+    const uint32_t* const rec = sa.recs + (size_t)k * sa.tokcap;
 
     constexpr uint32_t nt = 256;  // (the launcher's block size: a constant keeps divisions by it shifts)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -446,13 +444,6 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     LdsCtl* const ctl = (LdsCtl*)(lagl + 2 * kSplitMaxLag);
 
     for (uint32_t i = tid; i < 2 * nlag; i += nt) lagl[i] = sa.lag[(size_t)k * kSplitMaxLag * 2 + i];
-    if (sa.maxcap <= 4224u && ntok <= kSplitRecLds) {
-        // the records are read three times below, the third time one token at a time from a per-byte loop: bring them in once,
-        // coalesced (round 3)
-        uint32_t* const recl = reinterpret_cast<uint32_t*>(smem + capa + 16 + 2 * capa + kSplitMaxLag * 8 + 64);
-        for (uint32_t i = tid; i < ntok; i += nt) recl[i] = rec[i];
-        rec = recl;
-    }
     __syncthreads();
 
     // lag before the token that starts at output position O (all lagging tokens that END at or before O)
