@@ -257,6 +257,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.n_streams = (uint32_t)n_streams;
     a.prof = g_prof;
     a.work_counter = nullptr;
+    a.claim = 1;
     // epoch cut at long runs (extended format only: the v1 format has no RLE token), tamp_compress_kernel.hpp
     a.cut_run = conf->extended ? 6u : 0u;  // (doubles per stream whenever a cut turns out to be superfluous)
     if (const char* e = getenv("TAMP_AMD_CUT_RUN")) { const int v = atoi(e); a.cut_run = (conf->extended && v >= 2 && v <= 64) ? (uint32_t)v : 0u; }
@@ -316,12 +317,20 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     // the six builds: lazy (u32 / u16 entries), run-aware (generic window / 2^10 with the scan constants as immediates),
     // lean one-wavefront build for short messages (512 buckets: a quarter of the cursors to zero and scan per message),
-    // lean u16 build for the 2^15 window
-    auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true> : tamp_compress_kernel<false, true>)
-                  : !packed ? tamp_compress_kernel<false, false>
-                  : runlist ? (conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024> : tamp_compress_kernel<true, false, true>)
+    // lean u16 build for the 2^15 window.
+    // All but the short-message build run as a PERSISTENT GRID (LOOP in the kernel): as many workgroups as the device holds
+    // at once, each taking streams from a counter until none is left.  Workgroup i of a grid runs on XCD i % 8 whatever the
+    // other XCDs are doing, so with one workgroup per stream an eighth of the batch is pinned to each XCD before anything
+    // of the streams' costs is known -- and real text is heavy-tailed (and the frozen corpora, 768 chunks long, handed every
+    // XCD the same 96 chunks over and over: 17 % lost, profiles/ab/r3_persistent_grid.log).  Short messages keep one
+    // workgroup per stream: two million fetches from one counter cost more than the balance is worth (20 instead of
+    // 41 GB/s when tried), and their costs are even.
+    const bool short_build = packed && !a.lazy && !runlist;
+    auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true, false, 0, kHashBits, true> : tamp_compress_kernel<false, true, false, 0, kHashBits, true>)
+                  : !packed ? tamp_compress_kernel<false, false, false, 0, kHashBits, true>
+                  : runlist ? (conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHashBits, true> : tamp_compress_kernel<true, false, true, 0, kHashBits, true>)
                             : tamp_compress_kernel<true, false, false, 0, 9>;
-    if (packed && !a.lazy && !runlist && threads != 64) {  // (short messages only: long streams are run-aware above)
+    if (short_build && threads != 64) {  // (short messages only: long streams are run-aware above)
         snprintf(t_last_error, sizeof t_last_error, "no lean build for %u-thread workgroups", threads);
         return TAMP_AMD_BAD_ARGUMENT;
     }
@@ -329,26 +338,48 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
                                (int)L.total));
     g_last_encoder.store("epoch");
     timing_begin(st);
-#ifdef TAMP_STREAM_LOOP
-    {   // persistent grid: what the device holds at once, streams handed out by a counter
+    if (!short_build) {
+        static std::mutex occ_mu;
+        static std::map<std::pair<const void*, uint64_t>, int> occ;  // (the occupancy query costs ~10 us: once per shape)
         int per_cu = 0;
-        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), (int)threads, L.total));
-        if (per_cu < 1) per_cu = 1;
+        {
+            std::lock_guard<std::mutex> lock(occ_mu);
+            const auto key = std::make_pair(reinterpret_cast<const void*>(kernel), (uint64_t)L.total << 16 | threads);
+            auto it = occ.find(key);
+            if (it == occ.end()) {
+                HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), (int)threads, L.total));
+                if (per_cu < 1) per_cu = 1;
+                occ.emplace(key, per_cu);
+            } else {
+                per_cu = it->second;
+            }
+        }
         const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
         a.work_counter = ctx->work_counters + slot;
         HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
         a.first_stream = 0;
-        const uint32_t g = (uint32_t)std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, n_streams);
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), L.total, st, a);
+        // streams per fetch from the counter: one for 256-thread workgroups (streams of 1 KiB and more), sixteen for
+        // one-wavefront ones (lazy / 2^15-window / hinted short messages)
+        a.claim = threads == 256 ? 1u : 16u;
+        const size_t claims = (n_streams + a.claim - 1) / a.claim;
+        size_t g = std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, claims);
+        // TAMP_AMD_STATIC_GRID=1 (tuning): one workgroup per claim instead -- each takes its claim when it starts and finds
+        // the counter exhausted afterwards
+        if (getenv("TAMP_AMD_STATIC_GRID")) g = claims;
+        // (every workgroup fetches one claim beyond the last: the counter ends at (claims + g) * claim)
+        if ((claims + g) * a.claim > 0xFFFFFFFFull || g > 0x7FFFFFFFull) {
+            snprintf(t_last_error, sizeof t_last_error, "%zu streams: beyond the 32-bit work counter", n_streams);
+            return TAMP_AMD_BAD_ARGUMENT;
+        }
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)g), dim3(threads), L.total, st, a);
+    } else {
+        const size_t launch_step = grid;
+        for (size_t first = 0; first < n_streams; first += launch_step) {  // one stream per workgroup
+            a.first_stream = (uint32_t)first;
+            const uint32_t g = (uint32_t)std::min<size_t>(grid, n_streams - first);
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), L.total, st, a);
+        }
     }
-#else
-    const size_t launch_step = grid;
-    for (size_t first = 0; first < n_streams; first += launch_step) {  // one stream per workgroup
-        a.first_stream = (uint32_t)first;
-        const uint32_t g = (uint32_t)std::min<size_t>(grid, n_streams - first);
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), L.total, st, a);
-    }
-#endif
     timing_end(st);
     HIP_OK(hipGetLastError());
     return TAMP_OK;

@@ -60,7 +60,8 @@ struct CompressArgs {
     uint16_t lead;      // those bytes, first one in the high byte
     uint8_t seg_flags;  // kSegResume | kSegSave | kSegFlushToken
     uint8_t* state;     // per stream: (1 << wbits) + kSegStateExtra bytes, see kSegStateExtra
-    uint32_t* work_counter;    // TAMP_STREAM_LOOP builds: next stream index to hand out (zeroed before the launch)
+    uint32_t* work_counter;    // LOOP builds: next stream index to hand out (zeroed before the launch)
+    uint32_t claim;            // LOOP builds: streams a workgroup takes per fetch from the counter
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t cut_run;          // epoch cut: a run of this many aligned dwords of one byte ends the block (0 = off)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
@@ -574,76 +575,131 @@ enum : uint32_t { cAct = 0, cShift = 1, cP0 = 2, cPending = 3, cWp = 4, cNtok = 
 // inside that loop (v_readlane + s_nop per entry: 4 % of the kernel, the "same code, 4 % slower" builds of section 3.6
 // of DESIGN.md).  Making W a constant for the whole kernel lets the compiler unroll and hoist elsewhere and costs 50+
 // spilled VGPRs, hence the narrow use.
-template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits>
-__global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a) {
+// LOOP: persistent workgroups that take stream after stream from a counter (the launcher starts as many as the device
+// holds) instead of one workgroup per stream.  Round 3: the hardware deals the workgroups of a grid to the eight XCDs round
+// robin by index -- a STATIC eighth of the batch each -- so with streams of unequal cost (real text) the XCDs finish up to
+// a fifth apart; with the counter an XCD that is ahead simply takes more streams: prose +27 %, Python sources +11 % at
+// 65,536 x 4 KiB, synthetic text -1 % (the loop keeps a few more values alive).  Short messages cost the same all over and
+// two million fetches from one address were a bottleneck: their build stays one workgroup per message.
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+    // (through the integer: a plain generic -> global -> generic pair of casts is folded away before it can tell anything)
+    return (T*)(__attribute__((address_space(1))) T*)reinterpret_cast<uintptr_t>(p);
+}
+
+template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false>
+__global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a_k) {
     // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
     constexpr uint32_t kRem = 16 - HB, kBuckets = 1u << HB;
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t a_wbits = a.wbits, a_blk = a.blk;
-    const uint32_t W = 1u << a_wbits, mask = W - 1;
-    constexpr bool lazy = LAZY;
-    const CompressLds L(W, a_blk, PACKED, lazy, RUNS);
-    uint8_t* const ebuf = smem + L.ebuf;
-    uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
-    uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
-    uint32_t* const ent = reinterpret_cast<uint32_t*>(smem + L.ent);
-    uint16_t* const ent16 = reinterpret_cast<uint16_t*>(smem + L.ent);
-    uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
-    uint16_t* const jump16 = reinterpret_cast<uint16_t*>(smem + L.ent + L.jump);   // alias, same reason
-    uint8_t* const count8 = smem + L.ent + L.count;                                 // alias, same reason
-    uint32_t* const jc32 = reinterpret_cast<uint32_t*>(smem + L.ent + L.jump);      // default parse: jump | count << 16
-    uint8_t* const vstep = smem + L.ent + L.vstep;  // lazy builds: transition of every (position, state), same alias
-    uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
-    // RUNS builds: bytes consumed by the tokens the match phase settles completely (short RLE runs, extended matches
-    // without a rival): second half of the cursor space, behind the 256 explicit pieces of `stok`; written after the
-    // match loops (when `sorted` is dead), read by the jump tables, the walk's token listing and the emitter
-    uint8_t* const xcnt = smem + L.cnt + kSlowCap * 8;
-    uint8_t* const blen = smem + L.blen;
-    uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
-    uint8_t* const blen2 = smem + L.blen2;                                    // only carved when lazy
-    uint16_t* const bidx2 = reinterpret_cast<uint16_t*>(smem + L.bidx2);
-    uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
-    uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
-    uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
-    // (an explicit LDS pointer: the address-space inference leaves volatile accesses alone, and through a generic pointer
-    // every control word was a FLAT load with system scope followed by a full wait)
-    typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
-    LdsCtl* const ctl = (LdsCtl*)(smem + L.ctl);
-    uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 80);
-    // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
-    uint8_t* const codetab = smem + L.ctl + 80 + 256;
-    uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
-    uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
-
-    const uint32_t tid_k = threadIdx.x, nt = blockDim.x;
-    const uint32_t nt_log2 = nt == 256 ? 8u : 6u;  // (256 or 64 threads: divisions by the block size are shifts)
-    uint32_t tid = tid_k;
-    int lane = tid & (kWave - 1);
-    uint32_t wave = tid >> 6;
-    const uint32_t minp = (uint32_t)min_pattern_size((int)a_wbits, a.lbits);
-    const bool ext = a.extended != 0;
-    const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
-    const uint32_t wbits = a_wbits, lbits = a.lbits;
-    if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier of the first stream
-    if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier)
-
-    // One stream per workgroup (the launcher splits batches above 2^20 streams into several launches): with no
-    // stream loop around it the compiler need not keep the batch tables' pointers alive past this point.
-#ifdef TAMP_STREAM_LOOP
-    // Persistent workgroups: as many as fit the device at once, each fetching the next stream index from a counter until
-    // the batch is exhausted (dynamic: streams differ in cost, a static stride left the slowest workgroup 20 % behind).
-    for (;;) {
-        if (tid_k == 0) ctl[cNext] = atomicAdd(a.work_counter, 1u);
+    // LOOP builds: this workgroup's claim on the work counter (next stream, end of the claim, the stream in hand, start of
+    // the claim after this one) lives in the first four words of LDS -- the slack in front of `ebuf`, which is only ever read under a mask -- at an address
+    // that does not depend on the configuration
+    typedef __attribute__((address_space(3))) volatile uint32_t LdsWord;
+    LdsWord* const claim = (LdsWord*)smem;
+    if constexpr (LOOP) {
+        if (threadIdx.x == 0) {
+            const uint32_t nx = atomicAdd(a_k.work_counter, a_k.claim);
+            claim[2] = nx, claim[0] = nx + 1, claim[1] = nx + a_k.claim;
+        }
         __syncthreads();
-        const uint32_t s = Walk::uni(ctl[cNext]);
-        if (s >= a.n_streams) break;
-#else
-    const uint32_t s = blockIdx.x + a.first_stream;
-    {
-#endif
+    }
+    // LOOP builds (persistent grid, streams handed out by a counter): the arguments are read from the kernel-argument
+    // segment again for every stream, through a pointer the compiler cannot see through.  Hoisted, the nine table pointers
+    // and everything derived from the configuration stay in scalar registers across the whole stream body -- 25 more SGPR
+    // spills and one spilled VGPR; reloaded, the body allocates like the one-stream build's.
+    typedef const __attribute__((address_space(4))) uint32_t* KernArgs;
+    struct ArgWords { uint32_t w[sizeof(CompressArgs) / 4]; };
+    static_assert(sizeof(ArgWords) == sizeof(CompressArgs), "whole dwords");
+    KernArgs ap = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t wave_k = Walk::uni(threadIdx.x >> 6);
+    for (;;) {
+        ArgWords aw;
+        if constexpr (LOOP) {
+            asm volatile("" : "+s"(ap));
+#pragma unroll
+            for (uint32_t i = 0; i < sizeof(CompressArgs) / 4; i++) aw.w[i] = ap[i];
+        }
+        CompressArgs a_l = __builtin_bit_cast(CompressArgs, aw);
+        if constexpr (LOOP) {
+            // (pointers out of plain dwords are generic ones, and every access through them a FLAT instruction: say what
+            // the compiler knows by itself of a kernel argument)
+            a_l.in = as_global(a_l.in), a_l.in_off = as_global(a_l.in_off), a_l.in_len = as_global(a_l.in_len);
+            a_l.out = as_global(a_l.out), a_l.out_off = as_global(a_l.out_off), a_l.out_cap = as_global(a_l.out_cap);
+            a_l.out_len = as_global(a_l.out_len), a_l.status = as_global(a_l.status), a_l.dict = as_global(a_l.dict);
+            a_l.state = as_global(a_l.state), a_l.work_counter = as_global(a_l.work_counter), a_l.prof = as_global(a_l.prof);
+        }
+        const CompressArgs& a = LOOP ? a_l : a_k;
+        const uint32_t a_wbits = a.wbits, a_blk = a.blk;
+        const uint32_t W = 1u << a_wbits, mask = W - 1;
+        constexpr bool lazy = LAZY;
+        const CompressLds L(W, a_blk, PACKED, lazy, RUNS);
+        uint8_t* const ebuf = smem + L.ebuf;
+        uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
+        uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
+        uint32_t* const ent = reinterpret_cast<uint32_t*>(smem + L.ent);
+        uint16_t* const ent16 = reinterpret_cast<uint16_t*>(smem + L.ent);
+        uint16_t* const toklist = reinterpret_cast<uint16_t*>(smem + L.ent);  // alias: index is dead during the walk
+        uint16_t* const jump16 = reinterpret_cast<uint16_t*>(smem + L.ent + L.jump);   // alias, same reason
+        uint8_t* const count8 = smem + L.ent + L.count;                                 // alias, same reason
+        uint32_t* const jc32 = reinterpret_cast<uint32_t*>(smem + L.ent + L.jump);      // default parse: jump | count << 16
+        uint8_t* const vstep = smem + L.ent + L.vstep;  // lazy builds: transition of every (position, state), same alias
+        uint32_t* const stok = reinterpret_cast<uint32_t*>(smem + L.cnt);     // alias: cursors are dead during the walk
+        // RUNS builds: bytes consumed by the tokens the match phase settles completely (short RLE runs, extended matches
+        // without a rival): second half of the cursor space, behind the 256 explicit pieces of `stok`; written after the
+        // match loops (when `sorted` is dead), read by the jump tables, the walk's token listing and the emitter
+        uint8_t* const xcnt = smem + L.cnt + kSlowCap * 8;
+        uint8_t* const blen = smem + L.blen;
+        uint16_t* const bidx = reinterpret_cast<uint16_t*>(smem + L.bidx);
+        uint8_t* const blen2 = smem + L.blen2;                                    // only carved when lazy
+        uint16_t* const bidx2 = reinterpret_cast<uint16_t*>(smem + L.bidx2);
+        uint32_t* const obuf = reinterpret_cast<uint32_t*>(smem + L.obuf);
+        uint16_t* const qstart = reinterpret_cast<uint16_t*>(smem + L.obuf + 16);  // alias: bit buffer is idle during match
+        uint16_t* const sorted = reinterpret_cast<uint16_t*>(smem + L.cnt);        // alias: cursors are dead after the scatter
+        // (an explicit LDS pointer: the address-space inference leaves volatile accesses alone, and through a generic pointer
+        // every control word was a FLAT load with system scope followed by a full wait)
+        typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
+        LdsCtl* const ctl = (LdsCtl*)(smem + L.ctl);
+        uint32_t* const bins = reinterpret_cast<uint32_t*>(smem + L.ctl + 80);
+        // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
+        uint8_t* const codetab = smem + L.ctl + 80 + 256;
+        uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
+        uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
+
+        uint32_t tid_l = threadIdx.x;
+        if constexpr (LOOP) {
+            // the thread index put together again for every stream from the wavefront's number (one scalar register) and
+            // the lane's, behind volatile asm: seen as the loop invariant it is, the index -- and everything computed from it
+            // alone: table addresses, the prefix-code bytes -- is held in VGPRs across the whole stream body, and spilled
+            uint32_t lane_l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
+            asm volatile("" : "+s"(wave_k));
+            tid_l = (wave_k << 6) | lane_l;
+        }
+        const uint32_t tid_k = tid_l, nt = blockDim.x;
+        const uint32_t nt_log2 = nt == 256 ? 8u : 6u;  // (256 or 64 threads: divisions by the block size are shifts)
+        uint32_t tid = tid_k;
+        int lane = tid & (kWave - 1);
+        uint32_t wave = tid >> 6;
+        const uint32_t minp = (uint32_t)min_pattern_size((int)a_wbits, a.lbits);
+        const bool ext = a.extended != 0;
+        const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
+        const uint32_t wbits = a_wbits, lbits = a.lbits;
+        if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier (every stream writes the same)
+        if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier; every stream leaves it at zero)
+
+        uint32_t s, pre = 0;
+        if constexpr (LOOP) {
+            // this workgroup's next stream (chosen behind the previous one, below)
+            s = Walk::uni(claim[2]);
+            if (s >= a.n_streams) break;
+            if (tid_k == 0 && claim[0] == claim[1]) pre = atomicAdd(a.work_counter, a.claim);
+        } else {
+            s = blockIdx.x + a.first_stream;
+        }
         // per-stream table entries are wave-uniform but arrive through vector loads (the compiler cannot prove the
         // tables invariant): pin them to scalar registers, or the two base pointers sit in VGPR pairs -- and spill
         const uint8_t* const in = a.in + uni_u64(a.in_off[s]);
@@ -678,6 +734,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         const uint32_t word0 = a.nlead ? (uint32_t)a.lead << 16 : (c_nbits ? c_bits & (0xFFFFFFFFu << (32 - c_nbits)) : 0u);
         for (uint32_t k = tid; k < L.obuf_words; k += nt) obuf[k] = k == 0 ? __builtin_bswap32(word0) : 0;
 
+        if (LOOP && tid_k == 0 && claim[0] == claim[1]) claim[3] = pre;  // (behind the window's loads: no wait of its own)
         Walk wk;
         wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
@@ -1743,7 +1800,24 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             for (int i = 0; i < 16; i++) atomicAdd(&a.prof[i], pt[i]);
         }
 #endif
-        __syncthreads();  // ctl / LDS reuse by the next stream
+        if constexpr (LOOP) {
+            // the next stream of this workgroup's current claim, or the first of the next claim of a.claim consecutive
+            // streams (1 for long streams; short ones are claimed sixteen at a time: fewer fetches from the one counter).
+            // The next claim was fetched while the last stream of the current one was compressed (`pre`, above): a fetch
+            // from the one counter all workgroups share takes microseconds, and nothing of a stream can start before it.
+            // The claim lives in LDS: nothing of it stays in registers across the stream.
+            if (tid_k == 0) {
+                uint32_t nx = claim[0];
+                if (nx == claim[1]) {
+                    nx = claim[3];
+                    claim[1] = nx + a.claim;
+                }
+                claim[0] = nx + 1;
+                claim[2] = nx;
+            }
+        }
+        __syncthreads();  // ctl / LDS reuse by the next stream; the next stream's number
+        if constexpr (!LOOP) break;
     }
 }
 
