@@ -354,6 +354,10 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
                 per_cu = it->second;
             }
         }
+        if (const char* e = getenv("TAMP_AMD_GRID_PER_CU")) {  // (tuning)
+            if (atoi(e) > 0) per_cu = atoi(e);
+            else fprintf(stderr, "tamp_amd: %d workgroups of %u threads, %u B LDS per CU\n", per_cu, threads, L.total);
+        }
         const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
         a.work_counter = ctx->work_counters + slot;
         HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));

@@ -596,14 +596,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // LOOP builds: this workgroup's claim on the work counter (next stream, end of the claim, the stream in hand, start of
-    // the claim after this one) lives in the first four words of LDS -- the slack in front of `ebuf`, which is only ever read under a mask -- at an address
+    // the claim after this one once fetched) lives in the first four words of LDS -- the slack in front of `ebuf`, which is only ever read under a mask -- at an address
     // that does not depend on the configuration
     typedef __attribute__((address_space(3))) volatile uint32_t LdsWord;
+    constexpr uint32_t kNoClaim = 0xFFFFFFFFu;  // (the launcher keeps the counter below it)
     LdsWord* const claim = (LdsWord*)smem;
     if constexpr (LOOP) {
         if (threadIdx.x == 0) {
             const uint32_t nx = atomicAdd(a_k.work_counter, a_k.claim);
-            claim[2] = nx, claim[0] = nx + 1, claim[1] = nx + a_k.claim;
+            claim[2] = nx, claim[0] = nx + 1, claim[1] = nx + a_k.claim, claim[3] = kNoClaim;
         }
         __syncthreads();
     }
@@ -691,12 +692,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier (every stream writes the same)
         if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier; every stream leaves it at zero)
 
-        uint32_t s, pre = 0;
+        uint32_t s;
         if constexpr (LOOP) {
             // this workgroup's next stream (chosen behind the previous one, below)
             s = Walk::uni(claim[2]);
             if (s >= a.n_streams) break;
-            if (tid_k == 0 && claim[0] == claim[1]) pre = atomicAdd(a.work_counter, a.claim);
         } else {
             s = blockIdx.x + a.first_stream;
         }
@@ -734,7 +734,6 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         const uint32_t word0 = a.nlead ? (uint32_t)a.lead << 16 : (c_nbits ? c_bits & (0xFFFFFFFFu << (32 - c_nbits)) : 0u);
         for (uint32_t k = tid; k < L.obuf_words; k += nt) obuf[k] = k == 0 ? __builtin_bswap32(word0) : 0;
 
-        if (LOOP && tid_k == 0 && claim[0] == claim[1]) claim[3] = pre;  // (behind the window's loads: no wait of its own)
         Walk wk;
         wk.ebuf = ebuf, wk.blen = blen, wk.bidx = bidx, wk.toklist = toklist, wk.stok = stok;
         wk.W = W, wk.mask = mask, wk.wbits = wbits, wk.lbits = lbits, wk.minp = minp, wk.ext = ext;
@@ -1600,6 +1599,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     ctl[cNtok] = wk.ntok;
                     ctl[cExcess] = excess_tok;
                 }
+            } else if (LOOP && tid == 3 * kWave) {
+                // the other wavefronts wait for the walk: the last one fetches the workgroup's next claim meanwhile, if this
+                // stream is the last of the current one (a fetch from the one counter all workgroups share takes
+                // microseconds; behind the stream, nothing of the next one could start before it)
+                if (claim[0] == claim[1] && claim[3] == kNoClaim) claim[3] = atomicAdd(a.work_counter, a.claim);
             }
             __syncthreads();
             TAMP_PROF_MARK(3);
@@ -1803,14 +1807,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         if constexpr (LOOP) {
             // the next stream of this workgroup's current claim, or the first of the next claim of a.claim consecutive
             // streams (1 for long streams; short ones are claimed sixteen at a time: fewer fetches from the one counter).
-            // The next claim was fetched while the last stream of the current one was compressed (`pre`, above): a fetch
-            // from the one counter all workgroups share takes microseconds, and nothing of a stream can start before it.
-            // The claim lives in LDS: nothing of it stays in registers across the stream.
+            // The next claim was fetched during the walk (above), or is now (one-wavefront workgroups, streams without a
+            // walk).  The claim lives in LDS: nothing of it stays in registers across the stream.
             if (tid_k == 0) {
                 uint32_t nx = claim[0];
                 if (nx == claim[1]) {
                     nx = claim[3];
+                    if (nx == kNoClaim) nx = atomicAdd(a.work_counter, a.claim);
                     claim[1] = nx + a.claim;
+                    claim[3] = kNoClaim;
                 }
                 claim[0] = nx + 1;
                 claim[2] = nx;

@@ -394,6 +394,69 @@ def test_pieces_with_custom_dictionary_append_and_excess_bits(ta):
         ta.Compressor.PIECE_MIN = old_min
 
 
+def _ragged_batch(rng, n, max_len, empties=True):
+    """n streams of real text with a heavy-tailed length distribution (a few long ones among many short), some empty."""
+    from tamp_amd import workloads as wl
+
+    src = np.frombuffer(wl.real_text("python") + wl.real_text("prose"), dtype=np.uint8)
+    ln = np.minimum((rng.pareto(1.2, n) * 200).astype(np.int64) + 1, max_len)
+    if empties:
+        ln[rng.integers(0, n, max(1, n // 50))] = 0
+    start = rng.integers(0, len(src) - max_len, n)
+    off = np.zeros(n, np.uint64)
+    off[1:] = np.cumsum(ln[:-1])
+    flat = np.concatenate([src[a:a + k] for a, k in zip(start, ln)]) if ln.sum() else np.zeros(1, np.uint8)
+    return flat, off, ln.astype(np.uint32)
+
+
+@pytest.mark.parametrize("conf", [
+    dict(window=10, literal=8, extended=True),                        # run-aware build, 256 threads, one stream per claim
+    dict(window=10, literal=8, extended=True, lazy_matching=True),    # lazy build
+    dict(window=15, literal=8, extended=True),                        # u16 entries
+    dict(window=8, literal=8, extended=False),
+])
+def test_persistent_grid_hands_out_every_stream_once(ta, checker, conf, monkeypatch):
+    """The compress builds that run as a persistent grid (workgroups take streams from a counter until none is left): batches
+    whose size is no multiple of the claim, smaller than one claim, larger than the grid, with empty streams (no walk: the
+    next claim is fetched behind the stream instead of during it) and heavy-tailed lengths -- every stream byte for byte
+    against the reference, and the same bytes again with one workgroup per claim (TAMP_AMD_STATIC_GRID)."""
+    rng = np.random.default_rng(11)
+    for n, max_len in ((1, 5000), (5, 300), (17, 700), (1003, 900), (1537, 6000), (9001, 3000)):
+        flat, off, ln = _ragged_batch(rng, n, max_len)
+        ckw = {("lazy" if k == "lazy_matching" else k): v for k, v in conf.items()}
+        want = checker.compress_batch(flat, off, ln, threads=16, **ckw)
+        got = ta.compress_batch(flat, off, ln, **conf)
+        assert np.array_equal(np.asarray(got.status), np.asarray(want.status))
+        for i in range(n):
+            assert got.stream(i) == want.stream(i), (conf, n, i, int(ln[i]))
+    flat, off, ln = _ragged_batch(rng, 2500, 2000)
+    ref = ta.compress_batch(flat, off, ln, **conf)
+    monkeypatch.setenv("TAMP_AMD_STATIC_GRID", "1")
+    again = ta.compress_batch(flat, off, ln, **conf)
+    monkeypatch.delenv("TAMP_AMD_STATIC_GRID")
+    assert all(ref.stream(i) == again.stream(i) for i in range(2500))
+
+
+def test_persistent_grid_short_claims_of_sixteen(ta, checker):
+    """One-wavefront launches of the persistent builds (short messages with lazy matching / the run-aware hint) claim sixteen
+    streams per fetch: sizes around the claim, and the plain short-message build (one workgroup per stream) next to them."""
+    from tamp_amd import workloads as wl
+
+    rng = np.random.default_rng(12)
+    for n in (1, 15, 16, 17, 31, 33, 4099):
+        rows = wl.synth_text(n, 256)
+        ln = rng.integers(0, 257, n).astype(np.uint32)
+        off = (np.arange(n, dtype=np.uint64) * 256)
+        for kw in (dict(lazy_matching=True), dict(run_aware=True), dict()):
+            conf = dict(window=8, literal=8, extended=True)
+            conf.update({k: v for k, v in kw.items() if k != "run_aware"})
+            ckw = {("lazy" if k == "lazy_matching" else k): v for k, v in conf.items()}
+            want = checker.compress_batch(rows.reshape(-1), off, ln, threads=16, **ckw)
+            got = ta.compress_batch(rows.reshape(-1), off, ln, max_in_len=256, **conf, **({"run_aware": True} if "run_aware" in kw else {}))
+            for i in range(n):
+                assert got.stream(i) == want.stream(i), (kw, n, i)
+
+
 def test_bench_line_keeps_the_contract():
     """The driver's contract for bench.py (one JSON line): every field it reads, the roofline and cpu_baseline objects, the
     live counter passes, the real-text rates next to the headline."""

@@ -4,7 +4,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np, torch
 from tamp_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libtamp_amd_prof.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get('PROF_LIB', 'libtamp_amd_prof.so'))
 import tamp_amd
 from tamp_amd import workloads as wl
 lib = _lib.load()
