@@ -259,7 +259,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.work_counter = nullptr;
     a.claim = 1;
     // epoch cut at long runs (extended format only: the v1 format has no RLE token), tamp_compress_kernel.hpp
-    a.cut_run = conf->extended ? 6u : 0u;  // (doubles per stream whenever a cut turns out to be superfluous)
+    a.cut_run = conf->extended ? 3u : 0u;  // (doubles per stream whenever a cut turns out to be superfluous)
     if (const char* e = getenv("TAMP_AMD_CUT_RUN")) { const int v = atoi(e); a.cut_run = (conf->extended && v >= 2 && v <= 64) ? (uint32_t)v : 0u; }
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     const uint32_t W = 1u << conf->window;
