@@ -37,6 +37,14 @@ constexpr uint32_t kRunCap = 128;   // long runs listed per epoch (RUNS builds);
 #ifndef TAMP_LONG_RUN
 #define TAMP_LONG_RUN 8
 #endif
+#ifndef TAMP_DEFER_MIN
+#define TAMP_DEFER_MIN 24
+#endif
+// Extended format, default parse: a position INSIDE a short run of one byte (previous byte, this one and the next equal,
+// 2..6 of them ahead) whose bucket lists this many entries or more is not matched in the match phase: blen = kDeferred | slow.
+// The walk gets there only when a token happens to end inside the run -- rarely -- and asks Walk::best_on_demand then.
+constexpr uint32_t kDeferMin = TAMP_DEFER_MIN;
+constexpr uint32_t kDeferred = 0x1Fu;  // length field of blen: no real first match is longer than the 16-byte ring
 constexpr uint32_t kLongRun = TAMP_LONG_RUN;    // a run of one byte this long is listed; its interior leaves the bigram index
 constexpr uint32_t kSlowCap = 256;             // explicit (non-derivable) token pieces per walk segment
 
@@ -361,6 +369,55 @@ struct Walk {
     }
 
     enum { kStepOk = 0, kStepRebase = 1, kStepExcess = 2 };
+
+    // find_best_match (compressor_find_match_desktop.c) over the live window, candidates spread over the 64 lanes: for the
+    // positions the match phase left out (kDeferred).  Window index i = history offset r + window_pos; a match may not run
+    // past index W-1; longest, ties -> lowest index; the ring goes on with the oldest byte behind the newest (common_l).
+    // The result goes where the match phase would have put it (the position stays a slow one): called by the walk on
+    // arrival, in front of the step that may consult it.
+    __device__ void best_on_demand(uint32_t R) {
+        uint32_t idx, len;
+        const uint32_t maxp1 = ext ? minp + 11 + kExtExtraMax : minp + 13;
+        const uint32_t cap = min(R, maxp1);
+        const uint32_t wpv = wp();
+        // clean state (wr == rd): the buffer looks like the match phase's view of position q = wr -- window ebuf[q, q+W),
+        // input behind it -- so a candidate is compared the way the bucket scan compares one (16 bytes at once)
+        const uint32_t q = wr;
+        uint32_t P[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) P[jj] = uni(lds_u32_unaligned(ebuf, W + q + 4 * jj));
+        const uint32_t b01 = P[0] & 0xFFFFu;
+        uint32_t key = 0;
+        for (uint32_t r0 = (uint32_t)lane; r0 < W; r0 += 16 * kWave) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                if (k * kWave >= W) break;
+                const uint32_t r = r0 + k * kWave;
+                const bool valid = r < W;
+                // (offset W-1, the newest byte, pairs with the oldest one: left to the compare)
+                const bool hit = (lds_u32_unaligned(ebuf, q + (valid ? r : 0u)) & 0xFFFFu) == b01 || r == W - 1;
+                hits |= (uint32_t)(valid && hit) << k;
+            }
+            while (hits) {
+                const uint32_t k = (uint32_t)__builtin_ctz(hits);
+                hits &= hits - 1;
+                const uint32_t r = r0 + k * kWave, t = W - r;
+                const uint32_t i = (r + wpv) & mask, lim = W - i;
+                const uint32_t lw = t < 16 ? prefix_len_wrapped16(ebuf, q + r, t, W, P) : prefix_len16(ebuf, q + r, P);
+                const uint32_t l = min(lw, min(cap, lim));
+                if (l >= 2) key = max(key, (l << 16) | lim);
+            }
+        }
+        key = wave_max_u32(key);
+        len = key >> 16;
+        idx = key ? W - (key & 0xFFFFu) : 0u;
+        if (lane == 0) {
+            const_cast<uint8_t*>(blen)[rd] = (uint8_t)(len | 0x80u);
+            const_cast<uint16_t*>(bidx)[rd] = (uint16_t)idx;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 
     template <bool RB>
     __device__ __forceinline__ bool best(uint32_t& idx, uint32_t& len) {
@@ -997,6 +1054,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         const uint32_t x0 = P[0] ^ rep, x1 = (P[1] ^ rep) & 0x00FFFFFFu;
                         const uint32_t r = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : (x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : 7u);
                         in_run = r >= 7 || r >= R;  // the run reaches past the arbitration limit or to the end of the ring
+                        // a short run, with a crowded bucket: the walk asks when -- if -- it gets here (kDeferred)
+                        // (the marker travels in `key`: length field kDeferred, slow by the bytes' own rule below)
+                        if (!in_run && r >= 2 && (uint32_t)bidx[q] - (uint32_t)qstart[q] >= kDeferMin) in_run = true, key = kDeferred << 16;
                     }
 #ifdef TAMP_PROF
                     if (R >= minp && !in_run && !(a.dbg & 2)) {
@@ -1223,6 +1283,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             if (ext && ebuf[W + q - 1] == x && (min(rq, 7u) >= 7u || rq >= R)) continue;  // the RLE path owns it (no scan above either)
                             const uint32_t cap_len = R < maxp ? R : maxp;
                             const uint32_t sv = blen[q];
+                            if ((sv & 0x1Fu) == kDeferred) continue;  // (the walk asks)
                             uint32_t key = (sv & 0x1Fu) ? (((sv & 0x1Fu) << 16) | (W - (uint32_t)bidx[q])) : 0u;
                             const uint32_t key0 = key;
                             bool hit16 = false;  // a 16-byte hit the first pass did not see: a rival for an extended match
@@ -1311,6 +1372,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const uint32_t sv = blen[q];
                             if (!(sv & 0x80u)) continue;
                             const uint32_t len = sv & 0x1Fu;
+                            if (len == kDeferred) continue;  // (no match to weigh the run against: the state machine's)
                             const uint32_t leftq = n - (e_p0 + q);
                             if (partial && leftq < kRing) continue;  // (the call ends in front of this position)
                             const uint32_t wpq = (e_wp + q) & mask;  // window_pos when the walk arrives here clean
@@ -1515,6 +1577,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                             const unsigned long long t0 = __builtin_readcyclecounter();
                             const uint32_t ec0 = wk.ext_count;
 #endif
+                            if constexpr (!LAZY) {
+                                if (ext && wk.wr == wk.rd && wk.rd < nvalid && (Walk::uni(blen[wk.rd]) & 0x1Fu) == kDeferred)
+                                    wk.best_on_demand(leftp < kRing ? leftp : kRing);  // (a position the match phase left out)
+                            }
                             r = wk.template step<RUNS>(leftp < kRing ? leftp : kRing, leftp);
 #ifdef TAMP_PROF
                             pt[11] += 1;

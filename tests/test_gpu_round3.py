@@ -457,6 +457,35 @@ def test_persistent_grid_short_claims_of_sixteen(ta, checker):
                 assert got.stream(i) == want.stream(i), (kw, n, i)
 
 
+def test_short_runs_with_crowded_buckets_are_matched_on_arrival(ta, checker):
+    """Extended format: positions inside short runs of one byte (2..6 ahead, the previous byte the same) whose bigram bucket
+    is crowded are left out of the match phase and matched by the walk when a token happens to end inside the run
+    (Walk::best_on_demand).  Text made of short runs of a few bytes with words in between -- crowded buckets, tokens ending
+    everywhere -- at several windows, plus runs at the window's ends and the same data in the v1 format."""
+    rng = np.random.default_rng(21)
+    words = [b"self", b"return", b"def", b"x", b"if", b"else:", b"ab", b"for i in", b"=", b"()", b"\n"]
+    n, L = 384, 4096
+    rows = np.zeros((n, L), np.uint8)
+    for i in range(n):
+        parts, total = [], 0
+        fill = bytes([rng.choice([32, 32, 32, 45, 48])])
+        while total < L:
+            run = fill * int(rng.integers(2, 9)) if rng.random() < 0.7 else bytes([rng.choice([32, 45, 48])]) * int(rng.integers(2, 14))
+            w = words[int(rng.integers(0, len(words)))]
+            parts += [run, w]
+            total += len(run) + len(w)
+        rows[i] = np.frombuffer(b"".join(parts)[:L], np.uint8)
+    off = np.arange(n, dtype=np.uint64) * L
+    ln = np.full(n, L, np.uint32)
+    ln[::7] = rng.integers(1, L, len(ln[::7]))
+    for window in (8, 10, 12):
+        for ext in (True, False):
+            want = checker.compress_batch(rows.reshape(-1), off, ln, window=window, literal=8, extended=ext, threads=16)
+            got = ta.compress_batch(rows.reshape(-1), off, ln, window=window, literal=8, extended=ext)
+            for i in range(n):
+                assert got.stream(i) == want.stream(i), (window, ext, i)
+
+
 def test_bench_line_keeps_the_contract():
     """The driver's contract for bench.py (one JSON line): every field it reads, the roofline and cpu_baseline objects, the
     live counter passes, the real-text rates next to the headline."""
