@@ -43,6 +43,13 @@ constexpr uint32_t kRunCap = 128;   // long runs listed per epoch (RUNS builds);
 // Extended format, default parse: a position INSIDE a short run of one byte (previous byte, this one and the next equal,
 // 2..6 of them ahead) whose bucket lists this many entries or more is not matched in the match phase: blen = kDeferred | slow.
 // The walk gets there only when a token happens to end inside the run -- rarely -- and asks Walk::best_on_demand then.
+// Wavefront priorities (s_setprio): the kernel is bound by instruction issue, six workgroups share a CU, and what a
+// workgroup's wavefronts wait for at a barrier is the slowest of them getting its turn.  The bucket scan -- the bulk, four
+// wavefronts wide, no barrier inside -- runs at the lowest priority; the short phases between barriers (load, index, the
+// passes behind the scan, jump tables, emit) above it; the serial walk, one wavefront with three waiting for it, on top.
+// Same instructions, less waiting: synthetic text 6.66 -> 6.43 ms, prose 13.7 -> 13.2, Python sources 33.4 -> 32.7
+// (profiles/ab/r3_persistent_grid.log).
+constexpr int kPrioScan = 0, kPrioShort = 2, kPrioWalk = 3;
 constexpr uint32_t kDeferMin = TAMP_DEFER_MIN;
 constexpr uint32_t kDeferred = 0x1Fu;  // length field of blen: no real first match is longer than the 16-byte ring
 constexpr uint32_t kLongRun = TAMP_LONG_RUN;    // a run of one byte this long is listed; its interior leaves the bigram index
@@ -345,6 +352,10 @@ struct Walk {
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
                 if (k * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
+                // (uniform: no candidate of this and the later rounds is in range.  The walking wavefront shares its SIMD
+                // with five others: what a search costs is the instructions it issues -- ~4 k of its ~8 k cycles were these
+                // sixteen rounds -- and the candidates start at `pos`, half way up the window on average.)
+                if (uni(c0 - (uint32_t)lane) + k * kWave + cnt + 1 > W) break;
                 const uint32_t c = c0 + k * kWave;
                 const bool valid = c + cnt + 1 <= W;
                 const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
@@ -828,6 +839,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
             uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
             const uint8_t* const steps = LAZY ? vstep : blen;
             if (need_match) {
+                __builtin_amdgcn_s_setprio(kPrioShort);
                 // ---------------- load: ebuf[W + k] = in[e_p0 + k] ----------------
                 const uint32_t room = cur_blk + kRing + kPendMax;
                 const uint32_t nload = left < room ? left : room;
@@ -1012,6 +1024,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 TAMP_PROF_MARK(1);
 
                 // ---------------- match: find_best_match for every position of the block ----------------
+                __builtin_amdgcn_s_setprio(kPrioScan);
                 asm volatile("" : "+v"(tid));
                 lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
                 const uint32_t nq = nvalid - e_pending;
@@ -1347,6 +1360,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     }
                 }
                 __syncthreads();
+                __builtin_amdgcn_s_setprio(kPrioShort);
                 TAMP_FINE(f3);
 #ifdef TAMP_PROF
                 pt[6] += f0, pt[7] += f1, pt[8] += f2, pt[10] += niter;
@@ -1484,6 +1498,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
 
             // ---------------- walk: wave 0 ----------------
             if (wave == 0) {
+                // The walk is a chain of dependent steps in ONE wavefront while the other three of the workgroup wait for
+                // it, and it shares its SIMD with five wavefronts of other workgroups: let the issue arbiter prefer it
+                // (kPrioWalk; see kPrioScan for the scheme).
+                __builtin_amdgcn_s_setprio(kPrioWalk);
                 wk.nvalid = nvalid;
                 wk.ntok = 0, wk.ns = 0;
                 uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
@@ -1665,6 +1683,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     ctl[cNtok] = wk.ntok;
                     ctl[cExcess] = excess_tok;
                 }
+                __builtin_amdgcn_s_setprio(kPrioShort);
             } else if (LOOP && tid == 3 * kWave) {
                 // the other wavefronts wait for the walk: the last one fetches the workgroup's next claim meanwhile, if this
                 // stream is the last of the current one (a fetch from the one counter all workgroups share takes
