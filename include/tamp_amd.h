@@ -352,11 +352,6 @@ float tamp_amd_last_kernel_ms(void);
  * want the memory back.) */
 long long tamp_amd_trim(int device);
 
-/* Which compress kernel the most recent compress launch of this process used: "epoch" (tamp_compress_kernel.hpp, the
- * default) or "tile" (tamp_compress_tile_kernel.hpp, opt-in with TAMP_AMD_ENCODER=tile); "" before the first launch.
- * For tests and tuning: the bytes are the same either way. */
-const char *tamp_amd_last_encoder(void);
-
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,6 @@ SYMBOLS = (
     "tamp_amd_read_header",
     "tamp_amd_set_timing",
     "tamp_amd_last_kernel_ms",
-    "tamp_amd_last_encoder",
     "tamp_amd_trim",
     "tamp_amd_host_alloc",
     "tamp_amd_host_free",
@@ -166,7 +165,6 @@ def load() -> C.CDLL:
     lib.tamp_amd_set_timing.argtypes = [i32]
     lib.tamp_amd_set_timing.restype = None
     lib.tamp_amd_last_kernel_ms.restype = C.c_float
-    lib.tamp_amd_last_encoder.restype = C.c_char_p
     lib.tamp_amd_trim.argtypes = [i32]
     lib.tamp_amd_trim.restype = C.c_longlong
     lib.tamp_amd_host_alloc.argtypes = [sz]

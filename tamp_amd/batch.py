@@ -109,9 +109,11 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     torch CUDA uint8 tensor + CUDA ``in_off`` (int64) / ``in_len`` (int32) tensors (device, zero-copy).
     Stream ``i``'s output equals ``tamp.compress(stream_i, window=..., literal=..., dictionary=..., extended=...)``
     of the reference.  ``status[i]`` holds the reference's ``tamp_res`` code for that stream.
-    ``run_aware`` picks the kernel build (same bytes either way): True = the run-aware build (long runs listed once,
-    most extended matches settled without a search: faster for streams of 1 KiB and more), False = the lean build
-    (faster for short messages), None = the library decides by stream length (``max_in_len`` >= 1 KiB -> run-aware).
+    ``run_aware`` picks the kernel build for batches of SHORT messages (same bytes either way): True = the run-aware
+    build (long runs listed once, most extended matches settled without a search), False = the lean one-wavefront build
+    (faster for short messages), None = the lean build.  Streams of 1 KiB and more (``max_in_len`` >= 1024, or unknown)
+    always take the run-aware build since round 3 -- it was the faster one on every text measured -- and the argument
+    (like ``$TAMP_AMD_RUNS``) is ignored for them.
     ``reuse`` (device batches with an integer ``out_cap``): the result of an earlier call with the same stream count and
     capacity on the same device; its output slab and tables are overwritten instead of allocating new ones.
     """

@@ -23,7 +23,6 @@
 #include "tamp_amd.h"
 #include "tamp_compat.h"
 #include "tamp_compress_kernel.hpp"
-#include "tamp_compress_tile_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_split_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
@@ -103,7 +102,6 @@ thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
 thread_local bool t_ev_valid = false;
 
 thread_local char t_last_error[512] = "";
-std::atomic<const char*> g_last_encoder{""};  // tamp_amd_last_encoder()
 unsigned long long* g_prof = nullptr;  // -DTAMP_PROF builds: device buffer of per-phase cycle sums
 
 #define HIP_OK(expr)                                                                                      \
@@ -288,33 +286,6 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     const uint32_t threads = a.blk >= 1024 ? 256 : 64;
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
-    {
-        // Tile-ring build (tamp_compress_tile_kernel.hpp): windows up to 2^10, default parse, streams long enough for a
-        // 256-thread workgroup.  TAMP_AMD_ENCODER=epoch|tile forces one (tuning / tests).
-        // Opt-in (TAMP_AMD_ENCODER=tile): bit-exact, but measured slower than the epoch kernel on every corpus of round 3
-        // (profiles/ab/README.md: 72 k against 53.6 k VALU instructions per 4 KiB stream, eight latency-bound builds).
-        bool tile = false;
-        if (const char* e = getenv("TAMP_AMD_ENCODER")) {
-            // (whole streams only: the tile kernel knows neither launches that end without a flush nor carried state)
-            if (!strcmp(e, "tile")) tile = conf->window <= 10 && !a.lazy && !seg;
-        }
-        if (tile) {
-            const TileLds TL;
-            auto tk = conf->window == 10 ? tamp_compress_tile_kernel<10>
-                      : conf->window == 9 ? tamp_compress_tile_kernel<9> : tamp_compress_tile_kernel<8>;
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL.total));
-            g_last_encoder.store("tile");
-            timing_begin(st);
-            for (size_t first = 0; first < n_streams; first += grid) {
-                a.first_stream = (uint32_t)first;
-                const uint32_t g = (uint32_t)std::min<size_t>(grid, n_streams - first);
-                hipLaunchKernelGGL(tk, dim3(g), dim3(256), TL.total, st, a);
-            }
-            timing_end(st);
-            HIP_OK(hipGetLastError());
-            return TAMP_OK;
-        }
-    }
     // the six builds: lazy (u32 / u16 entries), run-aware (generic window / 2^10 with the scan constants as immediates),
     // lean one-wavefront build for short messages (512 buckets: a quarter of the cursors to zero and scan per message),
     // lean u16 build for the 2^15 window.
@@ -336,8 +307,6 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     }
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.total));
-    g_last_encoder.store("epoch");
-    timing_begin(st);
     if (!short_build) {
         static std::mutex occ_mu;
         static std::map<std::pair<const void*, uint64_t>, int> occ;  // (the occupancy query costs ~10 us: once per shape)
@@ -358,9 +327,6 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
             if (atoi(e) > 0) per_cu = atoi(e);
             else fprintf(stderr, "tamp_amd: %d workgroups of %u threads, %u B LDS per CU\n", per_cu, threads, L.total);
         }
-        const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
-        a.work_counter = ctx->work_counters + slot;
-        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
         a.first_stream = 0;
         // streams per fetch from the counter: one for 256-thread workgroups (streams of 1 KiB and more), sixteen for
         // one-wavefront ones (lazy / 2^15-window / hinted short messages)
@@ -375,8 +341,14 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
             snprintf(t_last_error, sizeof t_last_error, "%zu streams: beyond the 32-bit work counter", n_streams);
             return TAMP_AMD_BAD_ARGUMENT;
         }
+        // (every argument check lies in front of the event pair: a refused call leaves no half-recorded timing)
+        timing_begin(st);
+        const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
+        a.work_counter = ctx->work_counters + slot;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(kernel, dim3((uint32_t)g), dim3(threads), L.total, st, a);
     } else {
+        timing_begin(st);
         const size_t launch_step = grid;
         for (size_t first = 0; first < n_streams; first += launch_step) {  // one stream per workgroup
             a.first_stream = (uint32_t)first;
@@ -497,7 +469,14 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
             // their own batches keep most of it; a slice of 2^18 long streams needs ~3.7 GiB, and configs[3] cut into
             // uneven slices by a 4 GiB budget ran 6.5 instead of 5.1 ms); TAMP_AMD_SPLIT_SCRATCH_MB overrides
             size_t budget = (size_t)8 << 30, free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 4);
+            // (the slab this stream already holds is part of what the call may use: without it the budget -- and with it
+            // the slice size, hence the decode time -- of the second call on a shape differed from the first's)
+            size_t held = 0;
+            {
+                std::lock_guard<std::mutex> lock(g_mu);
+                held = ctx->slabs[st].split_bytes;
+            }
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max((free_b + held) / 4, held));
             else (void)hipGetLastError();
             if (const char* e = getenv("TAMP_AMD_SPLIT_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v << 20; }
             slice = std::min(slice, std::max<size_t>(budget / per, 4096));
@@ -883,7 +862,14 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
         HIP_OK(hipMemcpyAsync(b.status + ch.i0, s.status, cnt, hipMemcpyDeviceToHost, st));
         if (b.in_consumed) HIP_OK(hipMemcpyAsync(b.in_consumed + ch.i0, s.in_consumed, cnt * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        if (!ch.out_packed && ch.out_hi > ch.out_lo && !getenv("TAMP_AMD_NO_STAGED_COPYBACK") &&
+        // (staging pays when the extent is mostly produced bytes; a sparse or permuted batch can span gigabytes for a few
+        // megabytes of output -- those, and extents above 512 MiB of pinned memory per slot, take the merged copies below)
+        size_t produced = 0;
+        if (!ch.out_packed)
+            for (size_t i = ch.i0; i < ch.i1; i++) produced += b.out_len[i];
+        const size_t extent = ch.out_hi - ch.out_lo;
+        const bool stage_ok = extent <= ((size_t)512 << 20) && extent <= 8 * produced + ((size_t)1 << 20);
+        if (!ch.out_packed && ch.out_hi > ch.out_lo && stage_ok && !getenv("TAMP_AMD_NO_STAGED_COPYBACK") &&
             P.stage[j].need(ch.out_hi - ch.out_lo) == hipSuccess) {
             // One device-to-pinned transfer of the chunk's whole extent, then exactly the produced bytes of every stream
             // placed by the host: bytes between and behind the slabs are never written.  (One hipMemcpyAsync per stream,
@@ -1095,7 +1081,7 @@ const char* tamp_amd_version(void) { return "tamp_amd 0.1 (gfx950)"; }
 
 const char* tamp_amd_last_error(void) { return t_last_error; }
 
-#if defined(TAMP_PROF) || defined(TAMP_TILE_DBG)
+#if defined(TAMP_PROF)
 // debug-only: per-phase cycle counters (not part of the public header)
 int tamp_amd_prof_read(unsigned long long* out6) {
     if (!g_prof) {
@@ -1123,7 +1109,6 @@ void tamp_amd_host_free(void* p) {
 
 void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
 
-const char* tamp_amd_last_encoder(void) { return g_last_encoder.load(); }
 
 // Release the scratch the library keeps between calls on `device` (decoder window slabs, split-decoder records, header
 // pre-pass words: one set per HIP stream that ever decoded; the staging of the host-memory pipeline stays).  Every stream
@@ -2025,6 +2010,7 @@ tamp_res segment_core(const TampAmdConf* conf, int emit_header, int append_marke
     }
     DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_state, d_dict;
     const uint64_t zero = 0;
+    if ((uint64_t)prefix.size() + (uint64_t)input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;  // (32-bit stream lengths)
     const uint32_t ilen = (uint32_t)(prefix.size() + input_size);
     const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
     HIP_OK(d_in.alloc((size_t)ilen + 64));
@@ -2061,6 +2047,10 @@ tamp_res segment_core(const TampAmdConf* conf, int emit_header, int append_marke
     HIP_OK(hipMemcpyAsync(&status, d_st.p, 1, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(stbuf.data(), d_state.p, SS, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    // A piece that did not complete leaves window and carry as they came in, so its bytes must not count either: a caller
+    // that consumed them and offered the piece again would emit them twice.  (A finishing call keeps the reference's
+    // contract -- what fitted is delivered with TAMP_OUTPUT_FULL, compressor.c:65-75.)
+    if (!finish && status != TAMP_OK) olen = 0;
     if (olen) HIP_OK(hipMemcpy(output, d_out.p, olen, hipMemcpyDeviceToHost));
     if (output_written_size) *output_written_size = olen;
     if (status == TAMP_OK) {

@@ -3,11 +3,14 @@
 Run once in the build container:  python tests/golden/make_corpus.py
 Writes  tests/golden/corpus_prose.txt.xz   (licence texts + Debian copyright files found on this image)
         tests/golden/corpus_python.txt.xz  (CPython 3.10 standard-library sources found on this image)
+        tests/golden/corpus_markup.txt.xz  (round 4: HTML of the GDB manual that ROCm ships -- running prose inside markup,
+                                            the closest thing on this image to the metric's own corpus, enwik8 = wiki XML)
         tests/golden/corpus_manifest.json  (sizes, SHA-256 of the raw bytes, the file list)
 
 The fixtures are DATA for this repo's tests (no file of the reference repository goes in): public licence texts
 (/usr/share/common-licenses, verbatim redistribution permitted), the copyright files Debian ships next to every
-package, and PSF-licensed standard-library modules.  They replace the globbed stand-ins of round 2, which moved
+package, PSF-licensed standard-library modules, and the GFDL-licensed GDB manual (texinfo HTML under /opt/rocm/share/html/rocgdb).
+`python tests/golden/make_corpus.py markup` rebuilds one corpus and leaves the others' fixtures and manifest entries alone.  They replace the globbed stand-ins of round 2, which moved
 whenever DESIGN.md was edited and could be missing on another box.
 """
 import glob
@@ -41,11 +44,17 @@ def collect(patterns, limit):
 
 
 def main():
-    manifest = {}
+    import sys
+
+    mpath = os.path.join(HERE, "corpus_manifest.json")
+    manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     for name, patterns in (
         ("prose", ["/usr/share/common-licenses/*", "/usr/share/doc/*/copyright"]),
         ("python", ["/usr/lib/python3.10/*.py", "/usr/lib/python3.10/*/*.py"]),
+        ("markup", ["/opt/rocm/share/html/rocgdb/*.html"]),
     ):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         raw, files = collect(patterns, TARGET)
         assert len(raw) >= 2 << 20, (name, len(raw))
         path = os.path.join(HERE, f"corpus_{name}.txt.xz")

@@ -254,11 +254,44 @@ def test_frozen_corpora_match_their_manifest():
     `real_text` figures are committed data, not whatever the machine happens to hold."""
     from tamp_amd import workloads as wl
 
-    for name in ("prose", "python"):
+    for name in ("prose", "python", "markup"):
         raw = wl.frozen_corpus(name)  # raises when the SHA-256 of the manifest does not match
         assert len(raw) == 3 << 20
         assert wl.real_text(name, 1 << 20) == raw[: 1 << 20]
         assert wl.real_text(name, 64 << 20) == raw  # never topped up from the machine
+
+
+def test_corpus_probe_finds_plain_and_zipped_files_and_reports_what_it_tried(tmp_path):
+    """bench.py looks for the metric's own corpus (enwik8) by itself -- $TAMP_CORPUS, a list of directories (plain or
+    .zip), one guarded download -- and puts what it tried into config.corpus_probe.  Here: the
+    probe against temp directories, with a 1,000-byte stand-in for the 100,000,000-byte file; no network is touched."""
+    import zipfile
+
+    from tamp_amd import workloads as wl
+
+    want = 1000
+    empty, plain, zipped, wrong = (tmp_path / n for n in ("empty", "plain", "zipped", "wrong"))
+    for d in (empty, plain, zipped, wrong):
+        d.mkdir()
+    path, rec = wl.probe_corpus(env={}, dirs=[str(empty)], fetch=False, want_len=want)
+    assert path is None and rec["found"] is None and rec["fetch"] == "not attempted"
+    assert rec["tried"] == [str(empty / "enwik8"), str(empty / "enwik8.zip")]
+    (wrong / "enwik8").write_bytes(b"x" * (want - 1))  # wrong length: not the corpus
+    (plain / "enwik8").write_bytes(bytes(range(250)) * 4)
+    path, rec = wl.probe_corpus(env={}, dirs=[str(empty), str(wrong), str(plain)], fetch=False, want_len=want)
+    assert path == str(plain / "enwik8") and rec["found"] == path and str(wrong / "enwik8") in rec["tried"]
+    with zipfile.ZipFile(zipped / "enwik8.zip", "w", zipfile.ZIP_DEFLATED) as z:
+        z.writestr("readme.txt", "not it")
+        z.writestr("enwik8", bytes(range(250)) * 4)
+    out = tmp_path / "unpacked"
+    path, rec = wl.probe_corpus(env={}, dirs=[str(zipped)], fetch=False, fetch_to=str(out), want_len=want)
+    assert path == str(out / "enwik8") and open(path, "rb").read() == bytes(range(250)) * 4
+    # $TAMP_CORPUS comes first
+    path, rec = wl.probe_corpus(env={"TAMP_CORPUS": str(plain / "enwik8")}, dirs=[str(empty)], fetch=False, want_len=want)
+    assert path == str(plain / "enwik8") and rec["tried"][0] == path
+    # the default list and the URL are the ones the bench documents; the real length is enwik8's
+    assert wl.ENWIK8_URL.endswith("/dc/enwik8.zip") and wl.ENWIK8_PINS["len"] == 100_000_000
+    assert all(not d.startswith("/root/reference") for d in wl.CORPUS_PROBE_DIRS)  # (never read at run time)
 
 
 def test_helpers_against_values_recorded_from_the_reference():
