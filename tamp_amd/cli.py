@@ -1,4 +1,4 @@
-"""Command line of the package: ``python -m tamp_amd compress|decompress`` with the options of the reference's CLI.
+"""Command line of the package: ``python -m tamp_amd compress|decompress|build-dictionary`` with the options of the reference's CLI.
 
 Mirrors ``tamp/cli/main.py:115-232`` (``tamp compress`` / ``tamp decompress``: ``--input/-i``, ``--output/-o``,
 ``--window/-w``, ``--literal/-l``, ``--dictionary/-d``, ``--lazy-matching``, ``--extended`` / ``--no-extended``; stdin /
@@ -6,8 +6,9 @@ stdout when no path is given; "No data provided." on empty input) and its dictio
 dictionary file of exactly ``1 << window`` bytes is used as it is, a shorter one is raw effective bytes -- the seeded
 default fills the buffer and the file's contents are copied to its END -- a longer one is an error.  The codec work
 runs on the GPU through the same ``tamp_amd.compress`` / ``tamp_amd.decompress`` as everything else; there is no
-``--implementation`` choice to make.  ``build-dictionary`` (a corpus-driven offline tool, ``tamp/cli/build_dictionary.py``)
-is not part of the codec path and is not provided.
+``--implementation`` choice to make.  ``build-dictionary`` (``tamp/cli/build_dictionary.py:706-927``: a custom dictionary
+from a corpus of messages) is ``tamp_amd/build_dictionary.py``: same options and output contract, every whole-corpus
+evaluation one batch launch on the GPU.
 """
 from __future__ import annotations
 
@@ -74,6 +75,17 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument("--extended", action=argparse.BooleanOptionalAction, default=True)
         if name == "compress":
             p.add_argument("--lazy-matching", action=argparse.BooleanOptionalAction, default=False)
+    b = sub.add_parser("build-dictionary", help="Build a custom dictionary from a corpus of messages.")
+    b.add_argument("input", metavar="INPUT", help="directory of sample files, or one file cut at --delimiter")
+    b.add_argument("--output", "-o", default="dictionary.bin", help="binary dictionary file (effective bytes only)")
+    b.add_argument("--window", "-w", type=_bits(8, 15), default=10)
+    b.add_argument("--literal", "-l", type=_bits(5, 8), default=8)
+    b.add_argument("--extended", action=argparse.BooleanOptionalAction, default=True)
+    b.add_argument("--delimiter", default="\n", help="splits a single input file into samples (default: newline)")
+    b.add_argument("--trim-threshold", "-t", type=_bits(2, 1 << 15), default=None,
+                   help="shortest substring worth an entry (default: a few values are tried, the best one kept)")
+    b.add_argument("--target-fill", "-f", type=float, default=None, help="fraction of the window to fill (default: the knee)")
+    b.add_argument("--quiet", "-q", action="store_true")
     return ap
 
 
@@ -81,6 +93,20 @@ def main(argv=None) -> int:
     import tamp_amd
 
     args = build_parser().parse_args(argv)
+    if args.command == "build-dictionary":
+        from tamp_amd import build_dictionary as bd
+
+        if args.target_fill is not None and not 0.0 < args.target_fill <= 1.0:
+            print("tamp_amd: --target-fill must be in (0, 1]", file=sys.stderr)
+            return 2
+        try:
+            bd.build_dictionary_cli(args.input, args.output, window=args.window, literal=args.literal, extended=args.extended,
+                                    delimiter=args.delimiter.encode().decode("unicode_escape"), trim_threshold=args.trim_threshold,
+                                    target_fill=args.target_fill, quiet=args.quiet)
+        except ValueError as e:
+            print(f"tamp_amd: {type(e).__name__}: {e}", file=sys.stderr)
+            return 1
+        return 0
     src = args.input if args.input is not None else args.input_pos
     dst = args.output if args.output is not None else args.output_pos
     try:

@@ -1740,7 +1740,9 @@ tamp_res tamp_compress_stream(TampCompressor* compressor, tamp_read_t read_cb, v
     if (output_written_size) *output_written_size = 0;
     TampAmdEncoderState* s = enc_state(compressor);
     if (!enc_ready(s) || !compressor->window) return TAMP_ERROR;
-    const size_t kStreamBuffer = env_or("TAMP_AMD_STREAM_BUFFER_MB", 64) << 20;
+    // (TAMP_AMD_STREAM_BUFFER_BYTES, when set, names the buffer in bytes: measurements at the reference's own 32-byte pump size)
+    const size_t kStreamBuffer = env_or("TAMP_AMD_STREAM_BUFFER_BYTES", 0) >= 16 ? env_or("TAMP_AMD_STREAM_BUFFER_BYTES", 0)
+                                                                                  : env_or("TAMP_AMD_STREAM_BUFFER_MB", 64) << 20;
     constexpr size_t kChunk = 1 << 16;
     std::vector<unsigned char> in, out;
     size_t total_in = 0, total_out = 0;

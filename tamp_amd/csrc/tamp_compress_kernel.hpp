@@ -233,6 +233,7 @@ struct Walk {
     uint32_t dbg_lag_rle = 0, dbg_lag_ext = 0, dbg_lag_rle_short = 0;  // (instrumented builds)
     uint32_t ntok, ns;
     bool partial = false;  // kSegPartial: every slow step is ONE poll with a full 16-byte ring (no whole-run / whole-match shortcuts)
+    uint32_t dbg = 0;      // (instrumented builds: 0x400000 / 0x800000 skip the two searches -- wrong bytes, the time they cost)
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
     uint32_t lazy_idx, lazy_len;
@@ -347,6 +348,9 @@ struct Walk {
     // index" among the candidates >= the first match -- which one search with the whole look-ahead finds directly.
     __device__ void ext_search(uint32_t avail, uint32_t& npos, uint32_t& ncnt) {
         const uint32_t pos = ext_pos, cnt = ext_count;
+#ifdef TAMP_PROF
+        if (dbg & 0x400000u) { npos = pos, ncnt = cnt; return; }
+#endif
         const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
         // filter: the candidate's bytes cnt-3 .. cnt must equal the last three consumed bytes + the next input byte
         // (the consumed bytes ARE the pattern: input [rd-cnt, rd) == window[pos, pos+cnt))
@@ -396,6 +400,13 @@ struct Walk {
     // arrival, in front of the step that may consult it.
     __device__ void best_on_demand(uint32_t R) {
         uint32_t idx, len;
+#ifdef TAMP_PROF
+        if (dbg & 0x800000u) {
+            if (lane == 0) const_cast<uint8_t*>(blen)[rd] = 0x80u, const_cast<uint16_t*>(bidx)[rd] = 0;
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+#endif
         const uint32_t maxp1 = ext ? minp + 11 + kExtExtraMax : minp + 13;
         const uint32_t cap = min(R, maxp1);
         const uint32_t wpv = wp();
@@ -826,6 +837,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         // (a carried run / extended match: its bytes lead the input and count as consumed, like a pending token after a re-base)
         wk.rle_count = c_rle, wk.ext_count = c_ext, wk.ext_pos = c_extpos, wk.rd = c_rle + c_ext, wk.partial = partial;
         wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+#ifdef TAMP_PROF
+        wk.dbg = a.dbg;
+#endif
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         if (tid_k == 0) ctl[cCutThr] = a.cut_run;  // (read after the load phase's barrier)
         uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
@@ -1546,6 +1560,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     dbg_calls++;
 #endif
                     __builtin_amdgcn_wave_barrier();
+#ifdef TAMP_PROF
+                    // (0x200000: the listing without its chain of dependent reads -- valid positions, wrong tokens: the
+                    // time the chain costs)
+                    if ((a.dbg & 0x200000u) && (uint32_t)lane < nqueued) {
+                        uint32_t pp = segv & 0xFFFFu, slot = segv >> 16;
+                        for (uint32_t cleft = LAZY ? (uint32_t)count8[pp] : jc32[pp] >> 16; cleft; cleft--) toklist[slot++] = (uint16_t)pp++;
+                    } else
+#endif
                     if ((uint32_t)lane < nqueued) {
                         uint32_t pp = segv & 0xFFFFu;
                         uint32_t slot = segv >> 16;

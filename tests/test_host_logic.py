@@ -294,6 +294,61 @@ def test_corpus_probe_finds_plain_and_zipped_files_and_reports_what_it_tried(tmp
     assert all(not d.startswith("/root/reference") for d in wl.CORPUS_PROBE_DIRS)  # (never read at run time)
 
 
+def test_build_dictionary_pipeline_with_a_cpu_evaluator(tmp_path, oracle):
+    """`python -m tamp_amd build-dictionary` (tamp/cli/build_dictionary.py:706-927): the mining, packing,
+    tradeoff table and knee on a corpus of 600 telemetry messages, with the whole-corpus evaluation -- one GPU batch launch
+    per dictionary in the product -- replaced by the oracle here (CPU tier).  The file holds the effective bytes only,
+    `cli.load_dictionary` puts them at the end of a seeded window, and that window beats the seeded default by a wide margin."""
+    from tamp_amd import build_dictionary as bd, cli, workloads as wl
+
+    rows = wl.telemetry(600, 256)
+    corpus = [bytes(r).rstrip(b" ") for r in rows]
+    src = tmp_path / "messages.txt"
+    src.write_bytes(b"\n".join(corpus))
+    assert bd.read_corpus(src) == corpus
+    d = tmp_path / "as_files"
+    d.mkdir()
+    for i, s in enumerate(corpus[:5]):
+        (d / f"{i:03d}.bin").write_bytes(s)
+    (d / "empty.bin").write_bytes(b"")
+    assert bd.read_corpus(d) == corpus[:5]
+    with pytest.raises(ValueError):
+        bd.read_corpus(tmp_path / "nothing-here")
+
+    flat = np.frombuffer(b"".join(corpus), dtype=np.uint8)
+    ln = np.array([len(s) for s in corpus], np.uint32)
+    off = np.zeros(len(ln), np.uint64)
+    off[1:] = np.cumsum(ln[:-1].astype(np.uint64))
+
+    def total(dictionary):
+        r = oracle.compress_batch(flat, off, ln, window=8, literal=7, extended=True, threads=8,
+                                  dictionary=None if dictionary is None else bytes(dictionary))
+        assert (r.status == 0).all()
+        return int(r.out_len.astype(np.int64).sum()) - len(ln)
+
+    out = tmp_path / "dictionary.bin"
+    lines = []
+    res = bd.build_dictionary_cli(src, out, window=8, literal=7, trim_threshold=4, total=total, log=lambda *a: lines.append(" ".join(map(str, a))))
+    blob = out.read_bytes()
+    assert 0 < len(blob) == res["dictionary_bytes"] <= 256
+    assert res["with_dictionary"] < 0.75 * res["baseline"], res
+    window = cli.load_dictionary(out, 8, 7, True)
+    assert len(window) == 256 and bytes(window[-len(blob):]) == blob and total(window) == res["with_dictionary"]
+    assert any("<-- selected" in x for x in lines) and any(x.startswith("With dict:") for x in lines)
+    sizes = [s for s, _ in res["tradeoff"]]
+    assert sizes == sorted(sizes) and res["knee"] in sizes
+    # the pieces: savings table, packing order, knee
+    assert bd.bits_saved(2, 2, 10, 8, True) == 2 * 9 - (2 + 10) and bd.bits_saved(1, 2, 10, 8, True) == 0
+    assert bd.bits_saved(14, 2, 10, 8, True) == 14 * 9 - (7 + (2 - 1) + 3 + 10)  # extended match: symbol 13, code 0, 3 bits, offset
+    assert bd.bits_saved(14, 2, 10, 8, False) == 14 * 9 - (9 + 10)
+    w, eff = bd.pack([(b"late", 100.0, 0.9), (b"early", 100.0, 0.1), (b"dense", 400.0, 0.9)], 8, 8, True)
+    assert eff == 14 and bytes(w[-5:]) == b"dense" and bytes(w[-9:-5]) == b"late" and bytes(w[-14:-9]) == b"early"
+    assert bd.find_knee([(0, 1000), (10, 500), (20, 480), (30, 470)]) == 10
+    assert bd.find_knee([(0, 1000), (10, 900), (20, 800), (30, 700)]) == 30
+    a = cli.build_parser().parse_args(["build-dictionary", "corpus/", "-o", "d.bin", "-w", "8", "-l", "7", "-t", "4", "-f", "0.5", "-q", "--no-extended"])
+    assert (a.input, a.output, a.window, a.literal, a.trim_threshold, a.target_fill, a.quiet, a.extended) == ("corpus/", "d.bin", 8, 7, 4, 0.5, True, False)
+
+
 def test_helpers_against_values_recorded_from_the_reference():
     """tests/golden/helpers.json (make_helpers_golden.py): bit_size, compute_min_pattern_size and initialize_dictionary
     with non-default seeds, as the reference's own Python definitions answer (tamp/__init__.py:18-70)."""
