@@ -1512,7 +1512,16 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     const uint32_t sv = steps[b + lane];  // sentinels (0x80) beyond the last state
                     const bool slowp = (sv & 0x80u) != 0;
                     uint32_t stepv = LAZY ? (sv & 0x7Fu) : (sv >= minp ? (sv & 0x1Fu) : 1u);
-                    if constexpr (RUNS && PACKED) { if (sv & 0x20u) stepv = xcnt[b + lane]; }  // RLE run / extended match settled above
+                    if constexpr (RUNS && PACKED) {
+                        if (sv & 0x20u) stepv = xcnt[b + lane];  // RLE run / extended match settled above
+                        // Step table for the token listing (round 4): every position leaves the bytes its step consumes
+                        // in xcnt (settled tokens have theirs there already).  The listing runs in ONE wavefront with
+                        // three waiting for it and what it costs is the instructions it issues: with one byte read per
+                        // token instead of the step byte, its flag tests and a second read for settled tokens, the
+                        // kernel is 2.2 % faster on the synthetic text and 1.6 % on prose
+                        // (profiles/ab/r4_listing_step_table.log; two tokens per round trip on top: no further gain).
+                        if (b + lane < nv) xcnt[b + lane] = (uint8_t)stepv;
+                    }
                     // packed: target * 4 (relative target 0..97 as the byte offset ds_bpermute wants) | count << 10 |
                     // finished << 18.  A round is five VALU operations: the count field of the own state is added onto
                     // the state fetched from the target (which brings target, count and the finished bit along; counts
@@ -1573,6 +1582,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                         uint32_t slot = segv >> 16;
                         for (uint32_t cleft = LAZY ? (uint32_t)count8[pp] : jc32[pp] >> 16; cleft; cleft--) {
                             toklist[slot++] = (uint16_t)pp;
+                            if constexpr (RUNS && PACKED) {  // (the step table of the jump phase)
+                                pp += xcnt[pp];
+                                continue;
+                            }
                             const uint32_t sv = steps[pp];
                             if (RUNS && PACKED && (sv & 0x20u))
                                 pp += xcnt[pp];

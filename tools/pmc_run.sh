@@ -3,7 +3,7 @@
 # do not fit into one pass).  Summaries land in gpurun_out/pmc_$TAG; copy what is to be tracked into profiles/.
 #   usage (GPU box, repo root): TAG=r2a bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r3a}
+TAG=${TAG:-r4}
 OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 # ---- compress kernel (configs[1], the bench command) ----
@@ -31,7 +31,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dec2_stats -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o realtext_stats -- python tools/realtext.py > $OUT/realtext_stats.log 2>&1
 # ---- real text (frozen corpora, extended format) and configs[4] messages: instruction counters (round 3) ----
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
-for c in prose python; do
+for c in prose markup python; do
   CORPUS=$c EXT=1 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT -o realtext_${c}_sq -- python tools/one_corpus.py 32768 > $OUT/realtext_${c}_sq.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT -o c5_sq -- python tools/config5.py > $OUT/c5_sq.log 2>&1
