@@ -234,6 +234,12 @@ struct Walk {
     uint32_t ntok, ns;
     bool partial = false;  // kSegPartial: every slow step is ONE poll with a full 16-byte ring (no whole-run / whole-match shortcuts)
     uint32_t dbg = 0;      // (instrumented builds: 0x400000 / 0x800000 skip the two searches -- wrong bytes, the time they cost)
+    // Cooperative searches (256-thread workgroups): the walk is ONE wavefront and the other three wait for it at a barrier;
+    // a search is posted in the control words, every wavefront takes a quarter of the candidate rounds, and the four keys
+    // are combined by the walking one (kCoop* below; two s_barrier per search).
+    typedef __attribute__((address_space(3))) volatile uint32_t CtlWord;
+    CtlWord* ctlw = nullptr;
+    bool coop = false;
     bool lazy;           // lazy matching (compressor.c:576-619)
     bool lazy_valid;     // a match cached by the previous step's probe
     uint32_t lazy_idx, lazy_len;
@@ -346,11 +352,10 @@ struct Walk {
     // keeps the lowest candidate among the longest and only candidates at or above it stay alive, so the rounds
     // together select "longest common prefix with the input, capped by the window end and min+131; ties -> lowest
     // index" among the candidates >= the first match -- which one search with the whole look-ahead finds directly.
-    __device__ void ext_search(uint32_t avail, uint32_t& npos, uint32_t& ncnt) {
+    // Candidate rounds [4 * g0, 4 * g1) of the search (a round = one candidate per lane, 64 apart): the best key of this
+    // wavefront's lanes.  key = length << 16 | ~candidate: longest, ties -> lowest candidate, whatever the order of evaluation.
+    __device__ __forceinline__ uint32_t ext_search_rounds(uint32_t avail, uint32_t g0, uint32_t g1) const {
         const uint32_t pos = ext_pos, cnt = ext_count;
-#ifdef TAMP_PROF
-        if (dbg & 0x400000u) { npos = pos, ncnt = cnt; return; }
-#endif
         const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
         // filter: the candidate's bytes cnt-3 .. cnt must equal the last three consumed bytes + the next input byte
         // (the consumed bytes ARE the pattern: input [rd-cnt, rd) == window[pos, pos+cnt))
@@ -358,37 +363,87 @@ struct Walk {
         const uint32_t nextb = tail4 >> 24;
         const uint32_t wpv = wp();
         uint32_t key = 0;
-        // 16 candidates per lane and pass: 16 independent LDS reads (one round trip); survivors are verified
+        // 16 rounds per pass over 1,024 window positions, four at a time: independent LDS reads (one round trip), then
+        // the survivors are verified
         for (uint32_t c0 = pos + lane; c0 + cnt + 1 <= W; c0 += 16 * kWave) {
-            uint32_t hits = 0;
+            for (uint32_t g = g0; g < g1; g++) {
+                if (4 * g * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
+                // (uniform: no candidate of this and the later rounds is in range.  What a search costs is the instructions
+                // it issues, and the candidates start at `pos`, half way up the window on average.)
+                if (uni(c0 - (uint32_t)lane) + 4 * g * kWave + cnt + 1 > W) break;
+                uint32_t hits = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                if (k * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
-                // (uniform: no candidate of this and the later rounds is in range.  The walking wavefront shares its SIMD
-                // with five others: what a search costs is the instructions it issues -- ~4 k of its ~8 k cycles were these
-                // sixteen rounds -- and the candidates start at `pos`, half way up the window on average.)
-                if (uni(c0 - (uint32_t)lane) + k * kWave + cnt + 1 > W) break;
-                const uint32_t c = c0 + k * kWave;
-                const bool valid = c + cnt + 1 <= W;
-                const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
-                bool hit = lds_u32_unaligned(ebuf, wr + r) == tail4;
-                if (r > W - 4) hit = ebuf[wr + ((r + 3) & mask)] == nextb;  // the four bytes straddle the write cursor
-                hits |= (uint32_t)(valid && hit) << k;
-            }
-            while (hits) {
-                const uint32_t k = (uint32_t)__builtin_ctz(hits);
-                hits &= hits - 1;
-                const uint32_t c = c0 + k * kWave;
-                if (c != pos && common_l(c, pos, cnt, true) < cnt) continue;  // (the current position matches itself)
-                const uint32_t cmax = min(maxp, W - c);
-                const uint32_t len = cnt + 1 + common_l(c + cnt + 1, 1, cmax - cnt - 1, false);
-                const uint32_t kk = (len << 16) | (0xFFFFu - c);
-                if ((kk >> 16) > (key >> 16)) key = kk;  // first-longest within this lane (c ascending)
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t c = c0 + (4 * g + j) * kWave;
+                    const bool valid = c + cnt + 1 <= W;
+                    const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
+                    bool hit = lds_u32_unaligned(ebuf, wr + r) == tail4;
+                    if (r > W - 4) hit = ebuf[wr + ((r + 3) & mask)] == nextb;  // the four bytes straddle the write cursor
+                    hits |= (uint32_t)(valid && hit) << j;
+                }
+                while (hits) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(hits);
+                    hits &= hits - 1;
+                    const uint32_t c = c0 + (4 * g + j) * kWave;
+                    if (c != pos && common_l(c, pos, cnt, true) < cnt) continue;  // (the current position matches itself)
+                    const uint32_t cmax = min(maxp, W - c);
+                    const uint32_t len = cnt + 1 + common_l(c + cnt + 1, 1, cmax - cnt - 1, false);
+                    key = max(key, (len << 16) | (0xFFFFu - c));
+                }
             }
         }
-        key = wave_max_u32(key);  // longest; ties -> lowest candidate
+        return wave_max_u32(key);
+    }
+
+    enum : uint32_t { kCoopCmd = 17, kCoopA = 1, kCoopB = 2, kCoopC = 3, kCoopD = 4, kCoopE = 18, kCoopF = 19, kCoopKey = 8 };  // ctl words (free during the walk)
+    enum : uint32_t { kCmdEnd = 0, kCmdExtSearch = 1, kCmdBest = 2 };
+
+    // find_extended_match (compressor.c:297-333), candidates spread over the 64 lanes -- of all four wavefronts when the
+    // workgroup has them.  `avail` = input bytes the search may look at.  The reference searches once per 16-byte ring
+    // refill (cap = count + ring); every round keeps the lowest candidate among the longest and only candidates at or
+    // above it stay alive, so the rounds together select "longest common prefix with the input, capped by the window end
+    // and min+131; ties -> lowest index" among the candidates >= the first match -- which one search with the whole
+    // look-ahead finds directly.
+    __device__ void ext_search(uint32_t avail, uint32_t& npos, uint32_t& ncnt) {
+#ifdef TAMP_PROF
+        if (dbg & 0x400000u) { npos = ext_pos, ncnt = ext_count; return; }
+#endif
+        uint32_t key;
+        if (coop) {
+            if (lane == 0) {
+                ctlw[kCoopA] = ext_pos, ctlw[kCoopB] = ext_count, ctlw[kCoopC] = avail, ctlw[kCoopD] = wr, ctlw[kCoopE] = rd, ctlw[kCoopF] = wp_e;
+                ctlw[kCoopCmd] = kCmdExtSearch;
+            }
+            __syncthreads();  // the request is posted: the helpers (Walk::serve) start on rounds 4..15
+            key = ext_search_rounds(avail, 0, 1);
+            __syncthreads();  // their keys are in
+            key = max(max(key, uni(ctlw[kCoopKey + 1])), max(uni(ctlw[kCoopKey + 2]), uni(ctlw[kCoopKey + 3])));
+        } else {
+            key = ext_search_rounds(avail, 0, 4);
+        }
         ncnt = key >> 16;
         npos = 0xFFFFu - (key & 0xFFFFu);
+    }
+
+    // Wavefronts 1-3 while wavefront 0 walks: wait for a request, take their quarter, hand the key back; leave when the
+    // walk posts kCmdEnd.  Every request is two barriers for all four wavefronts, the end is one.
+    __device__ void serve(uint32_t wave) {
+        for (;;) {
+            __syncthreads();
+            const uint32_t cmd = uni(ctlw[kCoopCmd]);
+            if (cmd == kCmdEnd) return;
+            const uint32_t avail = uni(ctlw[kCoopC]);  // (kCmdBest: the ring's bytes)
+            wr = uni(ctlw[kCoopD]), rd = uni(ctlw[kCoopE]), wp_e = uni(ctlw[kCoopF]);
+            uint32_t key;
+            if (cmd == kCmdBest) {
+                key = best_rounds(avail, wave, wave + 1);
+            } else {
+                ext_pos = uni(ctlw[kCoopA]), ext_count = uni(ctlw[kCoopB]);
+                key = ext_search_rounds(avail, wave, wave + 1);
+            }
+            if (lane == 0) ctlw[kCoopKey + wave] = key;
+            __syncthreads();
+        }
     }
 
     enum { kStepOk = 0, kStepRebase = 1, kStepExcess = 2 };
@@ -398,15 +453,8 @@ struct Walk {
     // past index W-1; longest, ties -> lowest index; the ring goes on with the oldest byte behind the newest (common_l).
     // The result goes where the match phase would have put it (the position stays a slow one): called by the walk on
     // arrival, in front of the step that may consult it.
-    __device__ void best_on_demand(uint32_t R) {
-        uint32_t idx, len;
-#ifdef TAMP_PROF
-        if (dbg & 0x800000u) {
-            if (lane == 0) const_cast<uint8_t*>(blen)[rd] = 0x80u, const_cast<uint16_t*>(bidx)[rd] = 0;
-            __builtin_amdgcn_wave_barrier();
-            return;
-        }
-#endif
+    // candidate rounds [4 * g0, 4 * g1) of that search: the best key (length << 16 | W - index) of this wavefront's lanes
+    __device__ __forceinline__ uint32_t best_rounds(uint32_t R, uint32_t g0, uint32_t g1) const {
         const uint32_t maxp1 = ext ? minp + 11 + kExtExtraMax : minp + 13;
         const uint32_t cap = min(R, maxp1);
         const uint32_t wpv = wp();
@@ -419,27 +467,53 @@ struct Walk {
         const uint32_t b01 = P[0] & 0xFFFFu;
         uint32_t key = 0;
         for (uint32_t r0 = (uint32_t)lane; r0 < W; r0 += 16 * kWave) {
-            uint32_t hits = 0;
+            for (uint32_t g = g0; g < g1; g++) {
+                if (4 * g * kWave >= W) break;
+                uint32_t hits = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                if (k * kWave >= W) break;
-                const uint32_t r = r0 + k * kWave;
-                const bool valid = r < W;
-                // (offset W-1, the newest byte, pairs with the oldest one: left to the compare)
-                const bool hit = (lds_u32_unaligned(ebuf, q + (valid ? r : 0u)) & 0xFFFFu) == b01 || r == W - 1;
-                hits |= (uint32_t)(valid && hit) << k;
-            }
-            while (hits) {
-                const uint32_t k = (uint32_t)__builtin_ctz(hits);
-                hits &= hits - 1;
-                const uint32_t r = r0 + k * kWave, t = W - r;
-                const uint32_t i = (r + wpv) & mask, lim = W - i;
-                const uint32_t lw = t < 16 ? prefix_len_wrapped16(ebuf, q + r, t, W, P) : prefix_len16(ebuf, q + r, P);
-                const uint32_t l = min(lw, min(cap, lim));
-                if (l >= 2) key = max(key, (l << 16) | lim);
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t r = r0 + (4 * g + j) * kWave;
+                    const bool valid = r < W;
+                    // (offset W-1, the newest byte, pairs with the oldest one: left to the compare)
+                    const bool hit = (lds_u32_unaligned(ebuf, q + (valid ? r : 0u)) & 0xFFFFu) == b01 || r == W - 1;
+                    hits |= (uint32_t)(valid && hit) << j;
+                }
+                while (hits) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(hits);
+                    hits &= hits - 1;
+                    const uint32_t r = r0 + (4 * g + j) * kWave, t = W - r;
+                    const uint32_t i = (r + wpv) & mask, lim = W - i;
+                    const uint32_t lw = t < 16 ? prefix_len_wrapped16(ebuf, q + r, t, W, P) : prefix_len16(ebuf, q + r, P);
+                    const uint32_t l = min(lw, min(cap, lim));
+                    if (l >= 2) key = max(key, (l << 16) | lim);
+                }
             }
         }
-        key = wave_max_u32(key);
+        return wave_max_u32(key);
+    }
+
+    __device__ void best_on_demand(uint32_t R) {
+        uint32_t idx, len;
+#ifdef TAMP_PROF
+        if (dbg & 0x800000u) {
+            if (lane == 0) const_cast<uint8_t*>(blen)[rd] = 0x80u, const_cast<uint16_t*>(bidx)[rd] = 0;
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+#endif
+        uint32_t key;
+        if (coop) {
+            if (lane == 0) {
+                ctlw[kCoopC] = R, ctlw[kCoopD] = wr, ctlw[kCoopE] = rd, ctlw[kCoopF] = wp_e;
+                ctlw[kCoopCmd] = kCmdBest;
+            }
+            __syncthreads();
+            key = best_rounds(R, 0, 1);
+            __syncthreads();
+            key = max(max(key, uni(ctlw[kCoopKey + 1])), max(uni(ctlw[kCoopKey + 2]), uni(ctlw[kCoopKey + 3])));
+        } else {
+            key = best_rounds(R, 0, 4);
+        }
         len = key >> 16;
         idx = key ? W - (key & 0xFFFFu) : 0u;
         if (lane == 0) {
@@ -837,6 +911,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
         // (a carried run / extended match: its bytes lead the input and count as consumed, like a pending token after a re-base)
         wk.rle_count = c_rle, wk.ext_count = c_ext, wk.ext_pos = c_extpos, wk.rd = c_rle + c_ext, wk.partial = partial;
         wk.ext_resolved = false, wk.ntok = 0, wk.ns = 0, wk.lane = lane;
+        wk.ctlw = (Walk::CtlWord*)ctl, wk.coop = nt == 256;
 #ifdef TAMP_PROF
         wk.dbg = a.dbg;
 #endif
@@ -1747,6 +1822,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                     ctl[cAct] = act;
                     ctl[cNtok] = wk.ntok;
                     ctl[cExcess] = excess_tok;
+                    ctl[Walk::kCoopCmd] = Walk::kCmdEnd;
                 }
                 __builtin_amdgcn_s_setprio(kPrioShort);
             } else if (LOOP && tid == 3 * kWave) {
@@ -1755,7 +1831,12 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(Compre
                 // microseconds; behind the stream, nothing of the next one could start before it)
                 if (claim[0] == claim[1] && claim[3] == kNoClaim) claim[3] = atomicAdd(a.work_counter, a.claim);
             }
-            __syncthreads();
+            // (256-thread workgroups: wavefronts 1-3 serve the walk's searches until it posts the end; the barrier that
+            // ends their service is the one wavefront 0 executes here)
+            if (wk.coop && wave != 0)
+                wk.serve(wave);
+            else
+                __syncthreads();
             TAMP_PROF_MARK(3);
 
             // ---------------- emit: token list -> bits (all threads) ----------------

@@ -26,7 +26,7 @@ copy("bench.json", f"{rnd}_bench.json")
 copy("stats_kernel_stats.csv", f"{rnd}_compress_kernel_stats.csv")
 for c in ("fetch", "write", "sq", "sq2"):
     counters(f"{c}_counter_collection.csv", f"{rnd}_pmc_{c}_counter_collection.csv")
-for c in ("prose", "python"):
+for c in ("prose", "markup", "python"):
     counters(f"realtext_{c}_sq_counter_collection.csv", f"{rnd}_pmc_realtext_{c}_sq_counter_collection.csv")
 counters("c5_sq_counter_collection.csv", f"{rnd}_pmc_configs4_sq_counter_collection.csv")
 for c in ("fetch", "write"):
@@ -39,7 +39,7 @@ counters("dec_split_sq_counter_collection.csv", f"{rnd}_pmc_decode_split_sq_coun
 copy("realtext_stats_kernel_stats.csv", f"{rnd}_realtext_kernel_stats.csv")
 with open(os.path.join(dst, f"{rnd}_decode_and_realtext_rates.txt"), "w") as fh:
     for f in ("dec4_stats.log", "dec2_stats.log", "realtext_stats.log", "config5.log", "short_msgs.log", "dec_split_pmc.log",
-              "realtext_prose_sq.log", "realtext_python_sq.log", "dec2_fetch.log"):
+              "realtext_prose_sq.log", "realtext_markup_sq.log", "realtext_python_sq.log", "dec2_fetch.log"):
         p = os.path.join(src, f)
         if os.path.exists(p):
             for line in open(p):
@@ -67,6 +67,7 @@ summ(f"{rnd}_pmc_sq2_counter_collection.csv", 65536, "configs[1]")
 summ(f"{rnd}_pmc_fetch_counter_collection.csv", 65536, "configs[1]")
 summ(f"{rnd}_pmc_write_counter_collection.csv", 65536, "configs[1]")
 summ(f"{rnd}_pmc_realtext_prose_sq_counter_collection.csv", 32768, "prose ext")
+summ(f"{rnd}_pmc_realtext_markup_sq_counter_collection.csv", 32768, "markup ext")
 summ(f"{rnd}_pmc_realtext_python_sq_counter_collection.csv", 32768, "python ext")
 summ(f"{rnd}_pmc_configs4_sq_counter_collection.csv", 2097152, "configs[4] share")
 summ(f"{rnd}_pmc_dec2_fetch_counter_collection.csv", 65536, "decode 65536x4K")

@@ -38,7 +38,7 @@ N = 16384
 py = wl.real_text('python')   # frozen fixtures (tests/golden/make_corpus.py)
 md = wl.real_text('prose')
 print(len(py), len(md))
-for name, blob in (("python sources (frozen)", py), ("prose (frozen)", md)):
+for name, blob in (("python sources (frozen)", py), ("prose (frozen)", md), ("markup (frozen)", wl.real_text('markup'))):
     n = len(blob)//4096
     if n == 0: continue
     rows = np.frombuffer(blob[:n*4096], dtype=np.uint8).reshape(n, 4096).copy()
