@@ -196,26 +196,29 @@ struct SegmentSpec {  // streaming Compressor over the engine: how this piece of
 };
 
 uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, bool runlist = false) {
-    // positions matched per epoch: the whole stream when it is short, else 2048 -- or 1536 when the smaller LDS
-    // footprint lets one more workgroup live on a CU (W = 1024: 25 KB instead of 30 KB, six instead of five; the extra
-    // occupancy outweighs the third epoch of a 4 KiB stream).  Always a multiple of 64 (the walk chases 64 positions
-    // per register).
+    // Positions matched per epoch (a multiple of 64: the walk chases 64 positions per register; of 256 when it can be:
+    // the index is scattered in tiles of 256 positions, two barriers each, and a last tile that is mostly empty costs
+    // as much as a full one).  The whole stream when it is short.  For longer ones what counts is how many workgroups a
+    // CU holds -- the kernel is bound by instruction issue and a third of a real-text stream's time is the one-wavefront
+    // walk -- so: the LARGEST block that still allows as many workgroups per CU as a 1,024-position block does (the
+    // registers allow TAMP_WG_PER_CU = 7 for the run-aware builds, 6 for the lean and 5 for the lazy ones).  At W = 1024
+    // that is 1,024 positions at seven per CU (21.4 KB; rounds 1-3: 1,536 at six, 26.3 KB): four epochs instead of three
+    // for a 4 KiB stream, and still faster on every input measured (profiles/ab/r4_seven_workgroups_per_cu.log).
     uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
     if (blk > 2048) blk = 2048;
-    if (blk > 1536) {
+    if (blk > 1024) {
         // (LDS is handed out in coarse granules: 26,960 B per workgroup measured as five per CU, 25,424 B as six)
         const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
-        if (lds_cu / align_up(CompressLds(W, 1536, packed, lazy, runlist).total, granule) >
-            lds_cu / align_up(CompressLds(W, blk, packed, lazy, runlist).total, granule))
-            blk = 1536;
-    }
-    if (lazy && blk > 1024) {
-        // lazy matching keeps a second table per position: at W = 1024 only 1024-position epochs leave room for five
-        // workgroups per CU, which is also what its 96 VGPRs allow (measured: 15.5 -> 13.8 ms on config 2)
-        const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
-        if (lds_cu / align_up(CompressLds(W, 1024, packed, lazy, runlist).total, granule) >= 5 &&
-            lds_cu / align_up(CompressLds(W, blk, packed, lazy, runlist).total, granule) < 5)
-            blk = 1024;
+        const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
+        auto per_cu = [&](uint32_t b) {
+            const uint32_t v = lds_cu / align_up(CompressLds(W, b, packed, lazy, runlist).total, granule);
+            return v < reg_cap ? v : reg_cap;
+        };
+        const uint32_t want = per_cu(1024);
+        uint32_t best = 1024;
+        for (uint32_t b = 1280; b <= 2048; b += 256)
+            if (b <= blk && per_cu(b) == want) best = b;
+        blk = best;
     }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;

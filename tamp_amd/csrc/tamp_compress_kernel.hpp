@@ -689,8 +689,20 @@ struct Walk {
     }
 };
 
-#ifndef TAMP_BRK_SHIFT  // block size after a break (tuning builds override)
-#define TAMP_BRK_SHIFT 1
+// Workgroups per CU the register allocation of the run-aware builds aims at.  Round 4: SEVEN (72 VGPRs, 5-7 of them spilled
+// to scratch outside the loops) with 1,024-position blocks (21.4 KB of LDS at w = 10) instead of six (80 VGPRs) with 1,536
+// (26.3 KB): a 4 KiB stream takes four epochs instead of three and the kernel is still 0.7 % faster on the synthetic text;
+// real text, whose workgroups spend a third of their time in the one-wavefront walk, gains 8-10 % from the seventh
+// (profiles/ab/r4_seven_workgroups_per_cu.log).  Eight (64 VGPRs) spills 92 registers.
+#ifndef TAMP_WG_PER_CU
+#define TAMP_WG_PER_CU 7
+#endif
+// Block size after a break (a token that wrote fewer bytes than it consumed threw the rest of the block away): with the
+// 1,536-position blocks of rounds 1-3 halving it (512 at least) was worth 15 % on real text; with 1,024-position blocks
+// at seven workgroups per CU the full block is the better guess again (prose 11.55 -> 10.9 ms, Python sources 28.3 -> 26.8,
+// profiles/ab/r4_seven_workgroups_per_cu.log).  Tuning builds override.
+#ifndef TAMP_BRK_SHIFT
+#define TAMP_BRK_SHIFT 0
 #define TAMP_BRK_MIN 512
 #endif
 enum : uint32_t { kActDone = 1, kActRebase = 2, kActContinue = 3 };
@@ -758,7 +770,7 @@ __device__ __forceinline__ T* as_global(T* p) {
 }
 
 template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false>
-__global__ void __launch_bounds__(256, LAZY ? 5 : 6) tamp_compress_kernel(CompressArgs a_k) {
+__global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) tamp_compress_kernel(CompressArgs a_k) {
     // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");

@@ -198,9 +198,13 @@ def test_cli_dictionary_rule_and_arguments(tmp_path):
 
 
 def test_compress_kernels_keep_everything_in_registers(tmp_path):
-    """The compress kernels run at the register limit of six workgroups per CU; a spilled VGPR costs a scratch store per
-    lane and stream (round 1: 40 % extra HBM traffic).  Compile the device code with the resource remarks on and require
-    0 spilled VGPRs / 0 B of scratch for every instantiation of tamp_compress_kernel (hipcc cross-compiles without a GPU)."""
+    """The compress kernels run at the register limit of their occupancy target; a spilled VGPR inside a loop costs a
+    scratch access per lane and iteration (round 1: 40 % extra HBM traffic).  Compile the device code with the resource
+    remarks on and require 0 spilled VGPRs / 0 B of scratch for every instantiation of tamp_compress_kernel -- except the
+    two run-aware builds, which since round 4 aim at SEVEN workgroups per CU (72 VGPRs): a handful of values that live
+    across a whole epoch are spilled there, a few dozen scratch instructions in 11,000, none in the bucket loop (the
+    bench's live HBM counter pass reads 1.14 x the algorithmic bytes with them, 1.04 x without).
+    (hipcc cross-compiles without a GPU)."""
     import os
     import re
     import shutil
@@ -224,7 +228,11 @@ def test_compress_kernels_keep_everything_in_registers(tmp_path):
         seen += 1
         spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
-        assert spill == 0 and scratch == 0, (name, spill, scratch)
+        if "ILb1ELb0ELb1E" in name:  # PACKED, not LAZY, RUNS: seven workgroups per CU
+            assert spill <= 8 and scratch <= 32, (name, spill, scratch)
+            assert "Occupancy [waves/SIMD]: 7" in b, name
+        else:
+            assert spill == 0 and scratch == 0, (name, spill, scratch)
     assert seen == 6, seen  # (round 3: six builds, DESIGN.md 3.6 -- five of them persistent-grid builds, trailing `Lb1E`)
     names = [b.split()[0] for b in blocks if "tamp_compress_kernel" in b.split()[0]]
     assert sum(n.endswith("Lb1EEEvNS_12CompressArgsE") for n in names) == 5, names
