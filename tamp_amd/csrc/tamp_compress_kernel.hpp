@@ -84,7 +84,7 @@ struct CompressArgs {
 
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
-    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, rbits, total;  // blen2/bidx2: lazy-matching probe results
+    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, runsx, rbits, total;  // blen2/bidx2: lazy-matching probe results
     uint32_t tokcap, obuf_words, jump, count, vstep;  // jump/count/vstep: byte offsets of the walk's tables inside `ent`
     __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false, bool runlist = false) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
@@ -124,6 +124,8 @@ struct CompressLds {
         // RUNS builds: the long runs of the epoch buffer (start | end << 16) and one bit per buffer position that
         // is left out of the bigram index (the interior of a listed run)
         runs = o;
+        if (runlist) o += kRunCap * 4;
+        runsx = o;  // per listed run: its byte | the two bytes behind it << 8 (what the second pass needs without touching ebuf)
         if (runlist) o += kRunCap * 4;
         rbits = o;
         if (runlist) o += align_up((W + blk + 96) / 8, 16);
@@ -850,6 +852,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
         // prefix codes by symbol for per-lane look-ups (the packed 64-bit constants would sit in four VGPRs all kernel long)
         uint8_t* const codetab = smem + L.ctl + 80 + 256;
         uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
+        uint32_t* const runsx = reinterpret_cast<uint32_t*>(smem + L.runsx);  // RUNS builds only
         uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
 
         uint32_t tid_l = threadIdx.x;
@@ -1057,6 +1060,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                     const uint32_t slot = atomicAdd((uint32_t*)&ctl[cNruns], 1u);
                                     if (slot < kRunCap) {
                                         runs[slot] = c | (e << 16);
+                                        runsx[slot] = x | ((lds_u32_unaligned(ebuf, e) & 0xFFFFu) << 8);
                                         for (uint32_t k = c + 1; k <= e - 4;) {  // bits [c+1, e-4]
                                             const uint32_t hiw = min(e - 4, k | 31u);
                                             const uint32_t m = (0xFFFFFFFFu << (k & 31u)) & (0xFFFFFFFFu >> (31u - (hiw & 31u)));
@@ -1458,26 +1462,51 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                 }
                             }
                             const uint32_t cz = q + ((0u - e_wp - q) & mask);  // the window position with index 0
+                            // Per listed run of the pattern's byte, interior candidates lo..hi (inside the window, in
+                            // front of its last 15 bytes).  With cs = b - rq, the candidate whose run remainder equals the
+                            // pattern's leading run:
+                            //   below cs   the match is exactly rq bytes wherever it starts -> the lowest window index
+                            //              decides: index 0 (cz) when it lies in the range, else the first one;
+                            //   cs itself  goes on behind the run: the two bytes behind the run (kept with the run record)
+                            //              against the pattern's two bytes behind ITS run decide whether the buffer has
+                            //              to be looked at at all;
+                            //   above cs   rc = b - c bytes, shrinking: the first one, or index 0 behind it (a larger
+                            //              limit W - index can outweigh the shorter run when the first one is clipped).
+                            // All of it is arithmetic on the run record, which is wave-uniform (one LDS read per run and
+                            // wavefront, kept on the scalar unit); round 4: Python sources 70 k -> ~25 k VALU
+                            // instructions per 4 KiB stream in this pass.
+                            const uint32_t qhi = q + W - 16;
+                            const uint32_t pb2 = lds_u32_unaligned(ebuf, W + q + (rq < 16 ? rq : 0u)) & 0xFFFFu;
 #pragma unroll 1
                             for (uint32_t k = 0; k < nruns; k++) {
-                                const uint32_t rv = runs[k], ra = rv & 0xFFFFu, rb = rv >> 16;
-                                if (ebuf[ra] != x) continue;
-                                const uint32_t lo = max(ra + 1, q), hi = min(rb - 4, q + W - 16);
-                                if (lo > hi) continue;
-                                const uint32_t cs = rb - rq;
-#pragma unroll 1
-                                for (uint32_t m = 0; m < 4; m++) {
-                                    const uint32_t c = m == 0 ? lo : (m == 1 ? cz : cs + (m - 2));
-                                    if (c < lo || c > hi || (m && c == lo)) continue;
-                                    const uint32_t lim_i = W - ((c + e_wp) & mask);
-                                    // run remainder at the candidate against the pattern's leading run: the shorter one
-                                    // ends the match (its next byte is not x, the other side's is) -- only equal runs
-                                    // go on behind the run and need the bytes compared.  (A run capped at the end of
-                                    // the indexed range has 16+ bytes left at every candidate: min() is still right.)
-                                    const uint32_t rc = rb - c;
-                                    uint32_t len = min(rc, rq);
-                                    if (rc == rq) len = prefix_len16(ebuf, c, P);
+                                const uint32_t rv = Walk::uni(runs[k]), rx = Walk::uni(runsx[k]);
+                                const uint32_t ra = rv & 0xFFFFu, rb = rv >> 16;
+                                const uint32_t lo = max(ra + 1, q), hi = min(rb - 4, qhi);
+                                if ((rx & 0xFFu) != x || lo > hi) continue;
+                                const int32_t cs = (int32_t)rb - (int32_t)rq;
+                                const bool cz_in = cz >= lo && cz <= hi;
+                                {   // below cs
+                                    const int32_t hiA = min((int32_t)hi, cs - 1);
+                                    if ((int32_t)lo <= hiA) {
+                                        const uint32_t c = cz_in && (int32_t)cz <= hiA ? cz : lo;
+                                        const uint32_t lim_i = W - ((c + e_wp) & mask);
+                                        key = max(key, (min(rq, min(cap_len, lim_i)) << 16) | lim_i);
+                                    }
+                                }
+                                if (cs >= (int32_t)lo && cs <= (int32_t)hi) {  // cs itself
+                                    const uint32_t x2 = (rx >> 8) ^ pb2;
+                                    uint32_t len = rq;
+                                    if (rq < 16 && !(x2 & 0xFFu)) len = (x2 >> 8) ? rq + 1 : prefix_len16(ebuf, (uint32_t)cs, P);
+                                    const uint32_t lim_i = W - (((uint32_t)cs + e_wp) & mask);
                                     key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
+                                }
+                                {   // above cs
+                                    const int32_t c1 = max((int32_t)lo, cs + 1);
+                                    if (c1 <= (int32_t)hi) {
+                                        const uint32_t lim_i = W - (((uint32_t)c1 + e_wp) & mask);
+                                        key = max(key, (min(rb - (uint32_t)c1, min(cap_len, lim_i)) << 16) | lim_i);
+                                        if (cz_in && (int32_t)cz > c1) key = max(key, (min(rb - cz, cap_len) << 16) | W);
+                                    }
                                 }
                             }
                             if (key != key0 || (hit16 && (sv & 0x40u))) {
