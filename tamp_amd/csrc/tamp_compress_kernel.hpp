@@ -84,7 +84,7 @@ struct CompressArgs {
 
 // LDS carve-up, shared by the host launcher and the kernel.
 struct CompressLds {
-    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, runsx, rbits, total;  // blen2/bidx2: lazy-matching probe results
+    uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, runsx, rxset, rbits, total;  // blen2/bidx2: lazy-matching probe results
     uint32_t tokcap, obuf_words, jump, count, vstep;  // jump/count/vstep: byte offsets of the walk's tables inside `ent`
     __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false, bool runlist = false) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
@@ -127,6 +127,8 @@ struct CompressLds {
         if (runlist) o += kRunCap * 4;
         runsx = o;  // per listed run: its byte | the two bytes behind it << 8 (what the second pass needs without touching ebuf)
         if (runlist) o += kRunCap * 4;
+        rxset = o;  // one bit per byte value: a listed run of that byte exists in this epoch
+        if (runlist) o += 32;
         rbits = o;
         if (runlist) o += align_up((W + blk + 96) / 8, 16);
         total = o;
@@ -853,6 +855,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
         uint8_t* const codetab = smem + L.ctl + 80 + 256;
         uint32_t* const runs = reinterpret_cast<uint32_t*>(smem + L.runs);    // RUNS builds only
         uint32_t* const runsx = reinterpret_cast<uint32_t*>(smem + L.runsx);  // RUNS builds only
+        uint32_t* const rxset = reinterpret_cast<uint32_t*>(smem + L.rxset);  // RUNS builds only
         uint32_t* const rbits = reinterpret_cast<uint32_t*>(smem + L.rbits);  // RUNS builds only
 
         uint32_t tid_l = threadIdx.x;
@@ -1039,6 +1042,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         // range (any run remainder > 16 acts the same).
                         for (uint32_t k = tid; k < (W + a_blk + 96) / 32; k += nt) rbits[k] = 0;
                         if (tid == 0) ctl[cNruns] = 0;
+                        if (tid < 8) rxset[tid] = 0;
                         __syncthreads();
                         if (tid == 0) ctl[cQuad] = 0;  // (everybody has read it: for the next epoch)
                         const uint32_t lim = NE + 16;
@@ -1061,6 +1065,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                     if (slot < kRunCap) {
                                         runs[slot] = c | (e << 16);
                                         runsx[slot] = x | ((lds_u32_unaligned(ebuf, e) & 0xFFFFu) << 8);
+                                        atomicOr(&rxset[x >> 5], 1u << (x & 31u));
                                         for (uint32_t k = c + 1; k <= e - 4;) {  // bits [c+1, e-4]
                                             const uint32_t hiw = min(e - 4, k | 31u);
                                             const uint32_t m = (0xFFFFFFFFu << (k & 31u)) & (0xFFFFFFFFu >> (31u - (hiw & 31u)));
@@ -1414,6 +1419,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             const uint32_t b01 = lds_u32_unaligned(ebuf, W + q);
                             const uint32_t x = b01 & 0xFFu;
                             if (((b01 >> 8) & 0xFFu) != x) continue;
+                            // (only bytes that HAVE a listed run: "ll", "ee", "ss" start a pattern somewhere in nearly every
+                            // wavefront of queries, and one such lane used to take all 64 through the loop over the runs)
+                            if (!((rxset[x >> 5] >> (x & 31u)) & 1u)) continue;
                             const uint32_t leftq = n - (e_p0 + q);
                             const uint32_t R = leftq < kRing ? leftq : kRing;
                             if (R < minp) continue;

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/ab_libs.sh base cur al32 al64 al128 2>&1 | grep -v python > gpurun_out/e9_ab.log; cat gpurun_out/e9_ab.log
+bash tools/ab_libs.sh base cur > gpurun_out/e11_ab.log 2>&1; cat gpurun_out/e11_ab.log
