@@ -705,6 +705,9 @@ struct Walk {
 // 1,536-position blocks of rounds 1-3 halving it (512 at least) was worth 15 % on real text; with 1,024-position blocks
 // at seven workgroups per CU the full block is the better guess again (prose 11.55 -> 10.9 ms, Python sources 28.3 -> 26.8,
 // profiles/ab/r4_seven_workgroups_per_cu.log).  Tuning builds override.
+#ifndef TAMP_ALIGN_MIN  // shortest block the ring-end alignment may produce (tuning builds override; 65536 = off)
+#define TAMP_ALIGN_MIN 256
+#endif
 #ifndef TAMP_BRK_SHIFT
 #define TAMP_BRK_SHIFT 0
 #define TAMP_BRK_MIN 512
@@ -959,6 +962,19 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
             // positions this epoch matches: the block, or less when a long run of one byte cuts it short (below; the walk's
             // later passes over the same tables read the figure back)
             uint32_t nvalid = left < cur_blk ? left : cur_blk;
+            // Ring-end alignment (extended format).  An extended match that is being written when the window's write
+            // cursor reaches the end of the ring is clipped there (compressor.c:404-410): a lag, wherever the match started.
+            // Where the ring ends is known when the epoch starts -- block position W - window_pos -- so the block ends
+            // THERE when that is not too close: a clipped match then costs nothing (the epoch was over anyway) instead of the
+            // rest of the block's matches and an epoch of its own.  With 1,024-position blocks at W = 2^10 a stream without
+            // lags keeps its epochs on the ring's revolutions by itself; after an RLE lag the next block is the rest of the
+            // revolution.  Markup (1.2 clipped matches per 4 KiB), prose (0.7) and Python sources (1.0) gain; a guess about
+            // cost only, like the cut below.
+            if (ext && !LAZY) {
+                const uint32_t k0 = W - e_wp;
+                if (k0 >= TAMP_ALIGN_MIN && k0 < nvalid) nvalid = k0;
+            }
+            const uint32_t nplan = nvalid;  // (what the block would be without a cut)
             if (!need_match) nvalid = Walk::uni(ctl[cCut]);
             uint32_t nv = LAZY ? 2 * nvalid : nvalid;  // states the walk's tables cover (lazy: position x {fresh, cached})
             const uint8_t* const steps = LAZY ? vstep : blen;
@@ -1854,7 +1870,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // carried it through the run and the cut only cost an index build -- this stream's runs have to be
                     // twice as long from now on.  (Source code: indentation repeats the line above; prose: rules and
                     // table borders mostly do not.)
-                    if (nvalid < (left < cur_blk ? left : cur_blk) && !broke && wk.rd >= nvalid && lane == 0)
+                    if (nvalid < nplan && !broke && wk.rd >= nvalid && lane == 0)
                         ctl[cCutThr] = min(2u * (uint32_t)ctl[cCutThr], 64u);
                     wk.wp_e = wk.wp();
                     w_p0 += wk.rd - pending;

@@ -18,7 +18,7 @@ tag = os.path.basename(os.environ.get('TAMP_AMD_LIB', 'libtamp_amd.so'))
 print(tag, 'synthetic ext  min %.3f median %.3f ms' % run(wl.synth_text(N, 4096)), flush=True)
 print(tag, 'synthetic v1   min %.3f median %.3f ms' % run(wl.synth_text(N, 4096), extended=False), flush=True)
 rng = np.random.default_rng(5)
-for name in ('prose', 'python'):
+for name in ('prose', 'markup', 'python'):
     blob = wl.real_text(name); n = len(blob) // 4096
     base = np.frombuffer(blob[:n * 4096], dtype=np.uint8).reshape(n, 4096)
     rows = np.ascontiguousarray(base[rng.permutation(np.arange(N) % n)])

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/ab_libs.sh base cur > gpurun_out/e11_ab.log 2>&1; cat gpurun_out/e11_ab.log
+bash tools/ab_libs.sh al0 cur al128 al512 2>&1 | grep -v "v1" > gpurun_out/e13_ab.log; cat gpurun_out/e13_ab.log
