@@ -387,7 +387,20 @@ __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_of
     maxcap = wave_max_u32(maxcap);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, off);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
+    // one set of atomics per WORKGROUP: with one per wavefront, 16,384 wavefronts of a million-stream batch queued 65,536
+    // atomics on four addresses -- 0.39 ms for a pre-pass that reads 13 MB (round 4: block reduction through LDS)
+    __shared__ uint32_t red[4][4];
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0) red[wave][0] = m, red[wave][1] = longest, red[wave][2] = wsum, red[wave][3] = maxcap;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nw = blockDim.x >> 6;
+        for (uint32_t w = 1; w < nw; w++) {
+            m = red[w][0] > m ? red[w][0] : m;
+            longest = red[w][1] > longest ? red[w][1] : longest;
+            wsum += red[w][2];
+            maxcap = red[w][3] > maxcap ? red[w][3] : maxcap;
+        }
         if (m) atomicMax(result, m);
         atomicMax(result + 1, longest);
         atomicAdd(result + 2, wsum);
@@ -408,6 +421,7 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.seed_dicts = ctx->seed_dicts;
     a.scratch = nullptr;
     a.only_flagged = nullptr;
+    a.flagged_count = nullptr;
     a.n_streams = (uint32_t)n_streams;
     DeviceCtx::Slab* call_slab = nullptr;
     {
@@ -433,7 +447,7 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         uint32_t scan[4] = {0, 0, 0, 0};
         uint32_t& found = scan[0];
         HIP_OK(hipMemsetAsync(hdr_scan, 0, 16, st));
-        const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 8);
+        const uint32_t sg = (uint32_t)std::min<size_t>((n_streams + 255) / 256, (size_t)ctx->cu_count * 4);
         hipLaunchKernelGGL(tamp_header_scan_kernel, dim3(sg), dim3(256), 0, st, d_in, d_in_off, d_in_len, d_out_cap,
                            (uint32_t)n_streams, (uint32_t)max_wbits, hdr_scan);
         HIP_OK(hipMemcpyAsync(scan, hdr_scan, 16, hipMemcpyDeviceToHost, st));
@@ -449,12 +463,18 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     a.lds_row = 0;
     const bool valid_bits = max_wbits >= 8 && max_wbits <= 15;
     // Split decoder (tamp_decompress_split_kernel.hpp): parse one lane per stream without any window, resolve one
-    // workgroup per stream by pointer jumping; what it flags is decoded by the wave decoder afterwards.  Needs the
-    // pre-pass (longest stream and largest out_cap size its scratch and LDS).
-    // Taken for batches of streams of 512 compressed bytes and more (short messages: the lean lane decoder with its LDS rows
-    // is three to six times faster, tools/dec_bench.py) whose output slabs fit RESOLVE's LDS.
+    // workgroup (out_cap above 2 KiB) or one wavefront per stream by pointer jumping; what it flags is decoded by the wave
+    // decoder afterwards.  Needs the pre-pass (longest stream and largest out_cap size its scratch and LDS).
+    // Taken for batches of streams of 512 compressed bytes and more, and for most batches of short messages (below), whose
+    // output slabs fit RESOLVE's LDS.
     const bool split_fits = valid_bits && max_out_cap && max_out_cap <= kSplitMaxOut && longest_in != 0xFFFFFFFFu;
-    const bool want_split = force ? force_split : (longest_in >= 512 && n_streams >= 256);
+    // Short messages (round 4, with RESOLVE's wavefront-per-stream build and the parse's whole-stream ring): the split decoder
+    // has no window to set up, the lane decoders fill one per message -- from the caller's dictionary, or 2^9 bytes and more
+    // of the seeded one.  1 Mi x 256 B: custom dictionary at w = 8 1.30 against 2.18 ms, default window 2^10 2.01 against
+    // 6.13 ms, 1 Mi x 512 B at w = 9 3.2 against 20.4 ms; only w = 8 without a dictionary stays with the LDS lanes (1.65
+    // against 1.98 ms).  tools/dec_short.py.
+    const bool short_split = longest_in < 512 && (d_dict != nullptr || max_wbits >= 9);
+    const bool want_split = force ? force_split : ((longest_in >= 512 || short_split) && n_streams >= 256);
     if (want_split && split_fits) {
         SplitArgs sa;
         sa.maxcap = max_out_cap;
@@ -518,9 +538,15 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         sa.meta = reinterpret_cast<uint32_t*>(base + b_recs);
         sa.lag = reinterpret_cast<uint32_t*>(base + b_recs + b_meta);
         sa.flagged = base + b_recs + b_meta + b_lag;
+        sa.flagged_count = reinterpret_cast<uint32_t*>(sa.flagged + ((n_streams + 3) & ~(size_t)3));  // (inside the 64 bytes of slack)
+        HIP_OK(hipMemsetAsync(sa.flagged_count, 0, 4, st));
         sa.d = a;
-        const uint32_t lds = split_resolve_lds(max_out_cap);
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_decode_resolve_kernel),
+        // resolve: a workgroup per stream, or -- short messages, out_cap up to 1 KiB -- a wavefront per stream, four per workgroup
+        bool wave_resolve = max_out_cap <= kSplitWaveMaxOut;
+        if (const char* e = getenv("TAMP_AMD_SPLIT_WAVE_MAX")) wave_resolve = max_out_cap <= (uint32_t)atoi(e);  // (tuning)
+        const uint32_t lds = split_resolve_lds(max_out_cap) * (wave_resolve ? 4u : 1u);
+        auto resolve_kernel = wave_resolve ? tamp_decode_resolve_kernel<64, 4> : tamp_decode_resolve_kernel<256, 4>;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         timing_begin(st);
         for (size_t first = 0; first < n_streams; first += slice) {
@@ -532,10 +558,11 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
             if (const char* e = getenv("TAMP_AMD_SPLIT_SPW")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) sa.spw = (uint32_t)v; }
             const uint32_t pwaves = (sa.count + sa.spw - 1) / sa.spw;
             hipLaunchKernelGGL(tamp_decode_parse_kernel, dim3((pwaves + 3) / 4), dim3(256), split_parse_lds(256), st, sa);
-            hipLaunchKernelGGL(tamp_decode_resolve_kernel, dim3(sa.count), dim3(256), lds, st, sa);
+            hipLaunchKernelGGL(resolve_kernel, dim3(wave_resolve ? (sa.count + 3) / 4 : sa.count), dim3(256), lds, st, sa);
         }
         // leftovers: the wave decoder over the flagged streams only
         a.only_flagged = sa.flagged;
+        a.flagged_count = sa.flagged_count;
         const uint32_t waves = max_wbits <= 12 ? 4 : 1;
         const uint32_t wlds = decode_wave_lds(max_wbits, waves);
         size_t groups = (n_streams + waves - 1) / waves;
@@ -670,6 +697,7 @@ int launch_decompress_resume(DeviceCtx* ctx, uint8_t* d_states, size_t stride, u
     a.seed_dicts = ctx->seed_dicts;
     a.scratch = nullptr;
     a.only_flagged = nullptr;
+    a.flagged_count = nullptr;
     a.n_streams = (uint32_t)n_streams;
     a.lds_row = 0;
     a.max_wbits = bits_max;

@@ -40,6 +40,7 @@ struct DecompressArgs {
     uint8_t* scratch;           // global variant: one window slot of (1 << max_wbits) bytes per resident lane
     const uint8_t* only_flagged;  // null, or one byte per stream: decode only the streams whose byte is set (what the
                                   // split decoder, tamp_decompress_split_kernel.hpp, left over)
+    const uint32_t* flagged_count;  // with only_flagged: how many bytes are set (0: the kernel returns at once)
     uint32_t n_streams;
     uint32_t lds_row;           // LDS variant: bytes per lane row = (1 << max_wbits) + 4
     uint8_t max_wbits;

@@ -33,6 +33,7 @@
 namespace tamp_amd {
 
 constexpr uint32_t kSplitMaxLag = 48;      // lagging tokens listed per stream (more: the stream is left to the lane decoders)
+constexpr uint32_t kSplitWaveMaxOut = 2048;  // out_cap up to which RESOLVE runs one wavefront per stream (2 KiB: 1.25 against 1.31 ms for 131,072 streams; 4 KiB: 1.95 against 1.47)
 constexpr uint32_t kSplitMaxOut = 16384;   // bytes of output RESOLVE keeps in LDS (out_cap above: not a split-decoder batch)
 __host__ __device__ constexpr uint32_t split_resolve_lds(uint32_t maxcap) {
     // bytes + 16, one u16 pointer per byte, lag list, control words
@@ -50,6 +51,7 @@ struct SplitArgs {
     uint32_t* meta;          // n_streams
     uint32_t* lag;           // n_streams x kSplitMaxLag x 2: (Oend | Vend << 16), cumulative lag
     uint8_t* flagged;        // n_streams: 1 = left to the lane / wave decoders
+    uint32_t* flagged_count; // how many of them are set (the leftover launch returns at once when none is)
     uint32_t tokcap;         // records per stream
     uint32_t maxcap;         // largest out_cap of the batch (sizes RESOLVE's LDS)
     uint32_t first;          // first stream of this slice
@@ -182,14 +184,20 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         // consumed -- whatever it does not cover: the last ~32 input bytes, FLUSH, a token the output has no room for, an
         // out-of-bounds offset, a dry ring.  EXACT: the reference's own loop, rebuilt from the bit position (including the
         // refill cursor that decides the consumed count), takes two tokens and hands back, or finishes the stream.
-        const bool use_fast = n >= hs + 160;
+        // Short messages (round 4: a compressed 256-byte telemetry message is ~35 bytes): the WHOLE stream is put into the
+        // ring once -- dwords while they lie inside the stream, then bytes: nothing is read behind its end -- and the fast
+        // loop runs on it without any further input; only the tokens inside the last four bytes go to the exact loop.
+        // (Without this such batches ran the exact loop alone: 0.13 ms per 262,144 messages of parse.)
+        const bool whole = n <= kParseRing;
+        bool ring_loaded = false;
+        const bool use_fast = whole ? n >= hs + 8 : n >= hs + 160;
         for (;;) {
         bool resume = false;
         uint32_t budget = 0xFFFFFFFFu;
         if (use_fast) {
             uint32_t T = 8 * ip - nb;  // bits consumed from the start of the stream
-            const uint32_t sp = T >> 3;
-            bool fast = sp + 32 <= n;
+            const uint32_t sp = whole ? 0u : T >> 3;
+            bool fast = whole ? (T >> 3) + 4 <= n : sp + 32 <= n;
             const uint32_t sp0 = sp;  // stream byte x lives at inr[(x - sp0) & 63]
             // 25+ bits of the stream from bit position t, MSb first: two aligned dwords of the ring, funnel-shifted
             auto window = [&](uint32_t t) -> uint32_t {
@@ -200,7 +208,22 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
             B16 cb = {{0, 0, 0, 0}};
             bool cb_valid = false;
             uint32_t fill = sp, ld_off = sp;  // stream bytes [.., fill) are in the ring; next chunk to load
-            if (fast) {
+            if (fast && whole) {
+                if (!ring_loaded) {
+                    uint32_t x = 0;
+                    for (; x + 4 <= n; x += 4) {
+                        uint32_t v;
+                        __builtin_memcpy(&v, in + x, 4);
+                        *reinterpret_cast<uint32_t*>(inr + x) = v;
+                    }
+                    uint32_t tail = 0;
+                    for (uint32_t y = x; y < n; y++) tail |= (uint32_t)in[y] << (8 * (y - x));
+                    *reinterpret_cast<uint32_t*>(inr + x) = tail;  // (x <= 64: the mirror dword at most)
+                    ring_loaded = true;
+                }
+                fill = ld_off = n;  // (nothing more to load: the I/O points only empty the record stage)
+                budget = 2;
+            } else if (fast) {
                 const B16 c0 = ld16(in + sp);
                 st16(inr, c0);
                 st16(inr + 16, ld16(in + sp + 16));
@@ -414,15 +437,42 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
     if (a.in_consumed) a.in_consumed[s] = ip;
     sa.meta[k] = (ntok & 0xFFFFFu) | ((wbits - 8) << 20) | (dict_sel << 23) | ((nlag < 63 ? nlag : 63u) << 25) | (fallback ? kMetaFallback : 0u);
     sa.flagged[s] = fallback ? 1 : 0;
+    if (fallback) atomicAdd(sa.flagged_count, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // RESOLVE: records -> one pointer per output byte -> pointer jumping -> bytes
 // ---------------------------------------------------------------------------------------------------------------
+// NT = threads per stream: 256 (one workgroup per stream) or 64 (one WAVEFRONT per stream, four streams per workgroup, for
+// batches of short messages -- out_cap up to 1 KiB: a workgroup per 256-byte message is mostly barriers and idle lanes, and
+// the split decoder used to lose to the lane decoders by a factor of four there).  With NT = 64 nothing crosses a
+// wavefront: the barriers become wave barriers, the cross-wave sums fall away, each wavefront has its own slice of LDS.
+// BPT = consecutive output bytes a thread expands in the byte pass.  Rounds 2-3: 16 (4,096 bytes per round and workgroup); round 4:
+// FOUR -- 65,536 x 4 KiB 1.57 -> 1.47 ms, and a 256-byte message keeps all 64 lanes of its wavefront busy instead of 16
+// (1 M messages: 2.11 -> 1.29 ms); 1 / 2 / 8 measured: 1.68 / 1.58 / 1.45 ms at 4 KiB, 8 loses a quarter on short messages.
+template <uint32_t NT, uint32_t BPT = 4>
 __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     const DecompressArgs& a = sa.d;
-    const uint32_t k = blockIdx.x;
+    static_assert(NT == 256 || NT == 64, "a workgroup or a wavefront per stream");
+    static_assert(BPT == 16 || BPT == 8 || BPT == 4 || BPT == 2 || BPT == 1, "marks are read as one aligned group");
+    const uint32_t k = NT == 256 ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (NT == 64 && k >= sa.count) return;  // (whole wavefronts: no workgroup barrier below)
+    uint8_t* const smem = NT == 256 ? smem_all : smem_all + (threadIdx.x >> 6) * split_resolve_lds(sa.maxcap);
+    auto sync = [&]() {
+        if constexpr (NT == 256) {
+            __syncthreads();
+        } else {  // one wavefront: its LDS operations complete in order; keep the compiler from moving them across
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    auto sync_or = [&](int v) -> bool {
+        if constexpr (NT == 256) return __syncthreads_or(v) != 0;
+        sync();
+        return __ballot(v != 0) != 0;
+    };
     const uint32_t s = sa.first + k;
     const uint32_t meta = sa.meta[k];
     if (meta & kMetaFallback) return;  // decoded by the lane / wave decoders afterwards
@@ -433,8 +483,8 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     const uint8_t* const dict = dict_sel == 3 ? a.dict : a.seed_dicts + ((size_t)dict_sel << 15);
     const uint32_t* const rec = sa.recs + (size_t)k * sa.tokcap;
 
-    constexpr uint32_t nt = 256;  // (the launcher's block size: a constant keeps divisions by it shifts)
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    constexpr uint32_t nt = NT;  // (a constant keeps divisions by it shifts)
+    const uint32_t tid = threadIdx.x & (NT - 1), lane = tid & (kWave - 1), wave = tid >> 6;
     const uint32_t capa = align_up(sa.maxcap, 16);
     uint8_t* const outb = smem;                                             // capa bytes (+16)
     uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);    // capa entries: src[p] == p <=> outb[p] is final
@@ -444,7 +494,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     LdsCtl* const ctl = (LdsCtl*)(lagl + 2 * kSplitMaxLag);
 
     for (uint32_t i = tid; i < 2 * nlag; i += nt) lagl[i] = sa.lag[(size_t)k * kSplitMaxLag * 2 + i];
-    __syncthreads();
+    sync();
 
     // lag before the token that starts at output position O (all lagging tokens that END at or before O)
     auto lag_before_out = [&](uint32_t O) -> uint32_t {
@@ -469,7 +519,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     // threads), the marks inside its own 16 entries switch tokens on the way.  Each byte becomes either a final byte
     // (literal, dictionary) or a pointer to an earlier output byte.
     for (uint32_t i = tid; i < capa / 2; i += nt) reinterpret_cast<uint32_t*>(src)[i] = 0;
-    __syncthreads();
+    sync();
     {   // every thread takes a run of consecutive tokens: one prefix sum over the workgroup
         const uint32_t K = (ntok + nt - 1) / nt;
         const uint32_t j0 = min(tid * K, ntok), j1 = min(j0 + K, ntok);
@@ -477,7 +527,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         for (uint32_t j = j0; j < j1; j++) sum += (rec[j] >> 2) & 0xFFu;
         const uint32_t incl = wave_scan_add(sum);
         if (lane == kWave - 1) ctl[wave] = incl;
-        __syncthreads();
+        sync();
         uint32_t O = incl - sum;
         for (uint32_t w2 = 0; w2 < wave; w2++) O += ctl[w2];
         for (uint32_t j = j0; j < j1; j++) {  // (the records come from L1 the second time)
@@ -486,25 +536,37 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
             O += olen;
         }
     }
-    __syncthreads();
+    sync();
 #if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 1
     return;
 #endif
-    for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += 16 * nt) {  // 4,096 bytes per round
-        const uint32_t p0 = r0 + 16 * tid;
-        uint32_t h[8];  // this thread's 16 marks
-        {
+    for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += BPT * nt) {  // 4,096 bytes per round (NT = 256, BPT = 16)
+        const uint32_t p0 = r0 + BPT * tid;
+        uint32_t h[BPT >= 2 ? BPT / 2 : 1];  // this thread's marks
+        if constexpr (BPT == 16) {
             uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
             if (p0 < capa) lo = *reinterpret_cast<const uint4*>(src + p0), hi = *reinterpret_cast<const uint4*>(src + p0 + 8);
             h[0] = lo.x, h[1] = lo.y, h[2] = lo.z, h[3] = lo.w, h[4] = hi.x, h[5] = hi.y, h[6] = hi.z, h[7] = hi.w;
+        } else if constexpr (BPT == 8) {
+            uint4 lo = make_uint4(0, 0, 0, 0);
+            if (p0 < capa) lo = *reinterpret_cast<const uint4*>(src + p0);
+            h[0] = lo.x, h[1] = lo.y, h[2] = lo.z, h[3] = lo.w;
+        } else if constexpr (BPT == 4) {
+            uint2 lo = make_uint2(0, 0);
+            if (p0 < capa) lo = *reinterpret_cast<const uint2*>(src + p0);
+            h[0] = lo.x, h[1] = lo.y;
+        } else if constexpr (BPT == 2) {
+            h[0] = p0 < capa ? *reinterpret_cast<const uint32_t*>(src + p0) : 0u;
+        } else {
+            h[0] = p0 < capa ? (uint32_t)src[p0] : 0u;
         }
         uint32_t last = 0;  // position + 1 of this thread's last mark
 #pragma unroll
-        for (uint32_t i = 0; i < 16; i++)
+        for (uint32_t i = 0; i < BPT; i++)
             if ((h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) last = p0 + i + 1;
         const uint32_t inc = wave_scan_max(last);  // inclusive max-scan over the wave
         if (lane == kWave - 1) ctl[8 + wave] = inc;
-        __syncthreads();
+        sync();
         // last mark in front of this thread's bytes (position + 1): the scan shifted by one lane (DPP wave_shr:1, 0 into lane 0)
         uint32_t head = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);
         for (uint32_t w2 = 0; w2 < wave; w2++) head = max(head, (uint32_t)ctl[8 + w2]);
@@ -518,12 +580,12 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
         uint32_t jcur = 0;
         if (head) jcur = (head == carry_in && r0) ? (uint32_t)ctl[12] : (uint32_t)src[head - 1] - 1u;
         uint32_t hpos = head ? head - 1 : 0u;
-        __syncthreads();  // every mark has been read: `src` may be overwritten with pointers now
+        sync();  // every mark has been read: `src` may be overwritten with pointers now
         if (p0 < n_out) {
             // (a rolled loop over the thread's own LDS entries: unrolled over register copies it was 1,700 VALU
             // instructions of straight-line code for the 16 bytes)
             uint32_t kind = 0, arg = 0, Vj = 0;
-            const uint32_t pend = min(p0 + 16, n_out);
+            const uint32_t pend = min(p0 + BPT, n_out);
             if (head) {  // the token that reaches into this thread's bytes (a mark at p0 replaces it at once)
                 const uint32_t r = rec[jcur];
                 kind = r & 3u, arg = r >> 10;
@@ -554,7 +616,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
             // (the thread that owns the last byte of a full round also sees the token that reaches its end)
             if (tid == nt - 1) ctl[12] = jcur;  // the token that reaches the end of this round
         }
-        __syncthreads();
+        sync();
     }
 
 #if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 2
@@ -609,7 +671,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
             else if (q == 2) um2 = um;
             else um3 = um;
         }
-        if (!__syncthreads_or((int)(um0 | um1 | um2 | um3))) break;
+        if (!sync_or((int)(um0 | um1 | um2 | um3))) break;
     }
 
 #if defined(TAMP_SPLIT_STOP) && TAMP_SPLIT_STOP == 3

@@ -27,6 +27,7 @@ __host__ __device__ inline uint32_t decode_wave_lds(uint32_t max_wbits, uint32_t
 }
 
 __global__ void __launch_bounds__(256) tamp_decompress_wave_kernel(DecompressArgs a) {
+    if (a.only_flagged && a.flagged_count && *a.flagged_count == 0) return;  // (the split decoder left nothing over: the usual case)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const uint32_t wave = uni32(threadIdx.x >> 6);  // tell the compiler it is wave-uniform: the token loop goes scalar
