@@ -184,3 +184,50 @@ def test_build_dictionary_cli_end_to_end(tmp_path, ta):
     # reference: tamp/cli/main.py:208-216)
     assert cli.main(["decompress", str(tmp_path / "one.tamp"), str(tmp_path / "one.out"), "-w", "8", "-l", "7", "-d", str(out)]) == 0
     assert (tmp_path / "one.out").read_bytes() == corpus[7]
+
+
+def test_short_messages_through_the_split_decoder(ta, monkeypatch):
+    """Round 4: batches of short messages take the split decoder -- the parse keeps the whole compressed message in its
+    ring, RESOLVE runs one WAVEFRONT per stream (out_cap up to 2 KiB; four bytes per thread above it as well).  Telemetry
+    messages (window 2^8 + shared custom dictionary, the BASELINE configs[4] shape; default window 2^10), short text,
+    messages of 1..40 bytes, truncated streams, and every kind of restricted output -- status, bytes and consumed count
+    against the oracle's decoder, forced (`split`) and as the launcher picks (`auto`)."""
+    import random
+
+    from oracle.checker import Oracle
+    from tamp_amd import workloads as wl
+
+    oracle = Oracle()
+    rng = random.Random(41)
+    tel = wl.telemetry(600, 256)
+    d8 = wl.telemetry_dictionary(bytes(ta.initialize_dictionary(256, literal=7)))
+    groups = []  # (streams, dictionary, max_window_bits)
+    comp = [oracle.compress(tel[i].tobytes(), window=8, literal=7, dictionary=d8)[1] for i in range(300)]
+    groups.append((comp + [c[: rng.randrange(1, len(c))] for c in comp[:40]], d8, 15))
+    comp = [oracle.compress(tel[300 + i].tobytes())[1] for i in range(300)]  # default window, seeded dictionary
+    groups.append((comp + [c[: rng.randrange(1, len(c))] for c in comp[:40]], None, 15))
+    short = [wl.synth_text(1, rng.randrange(1, 41), first_index=i)[0].tobytes() for i in range(200)]
+    text = [wl.synth_text(1, rng.randrange(200, 2000), first_index=500 + i)[0].tobytes() for i in range(100)]
+    runs = [wl.lcg_runs(1, rng.randrange(100, 1500), first_index=i)[0].tobytes() for i in range(60)]  # RLE / extended tokens, lags
+    groups.append(([oracle.compress(x, window=9)[1] for x in short + text + runs], None, 15))
+    groups.append(([oracle.compress(x, window=10, extended=False)[1] for x in text[:60] + runs[:30]], None, 10))
+    checked = 0
+    for mode in ("split", "auto"):
+        if mode == "split":
+            monkeypatch.setenv("TAMP_AMD_DECODER", "split")
+        else:
+            monkeypatch.delenv("TAMP_AMD_DECODER", raising=False)
+        for streams, d, mwb in groups:
+            for cap in (2048, 600, 264, 256, 255, 100, 17, 1, 0):
+                res = ta.decompress_batch(streams, out_cap=cap, dictionary=d, max_window_bits=mwb)
+                for i, c in enumerate(streams):
+                    want = oracle.decompress(c, dictionary=d, cap=cap, max_window_bits=mwb)
+                    assert (int(res.status[i]), res.stream(i), int(res.in_consumed[i])) == want, (mode, cap, i, len(c))
+                    checked += 1
+            # ragged caps in one batch (the largest decides RESOLVE's build)
+            caps = np.array([rng.randrange(0, 1200) for _ in streams], dtype=np.uint32)
+            res = ta.decompress_batch(streams, out_cap=caps, dictionary=d, max_window_bits=mwb)
+            for i, c in enumerate(streams):
+                want = oracle.decompress(c, dictionary=d, cap=int(caps[i]), max_window_bits=mwb)
+                assert (int(res.status[i]), res.stream(i), int(res.in_consumed[i])) == want, (mode, "ragged", i)
+    assert checked > 20000
