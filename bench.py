@@ -536,7 +536,7 @@ def also_v1_and_decode(shard, res, torch):
     torch.cuda.synchronize(shard.device)
     back, best = None, 1e30
     with torch.cuda.device(shard.device):
-        for _ in range(3):
+        for _ in range(6):  # (the first call sizes the decoder's scratch slab)
             back = tamp_amd.decompress_batch(res.out, res.out_off, res.out_len, out_cap=shard.max_len, timing=True)
             best = min(best, float(back.kernel_ms))
     n = shard.n

@@ -1,2 +1,16 @@
-cd $GRAFT_REPO_ROOT
-bash tools/ab_libs.sh al0 cur al128 al512 2>&1 | grep -v "v1" > gpurun_out/e13_ab.log; cat gpurun_out/e13_ab.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for c in prose markup python synth; do
+OUT=gpurun_out/pmc_one_${c}_1; rm -rf $OUT; mkdir -p $OUT
+CORPUS=$c EXT=1 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq -- timeout 200 python tools/one_corpus.py 32768 2>&1 | grep "GB/s"
+done
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob('gpurun_out/pmc_one_*_1/*counter_collection.csv')):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'tamp_compress' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    m = {k: sum(v)/len(v) for k, v in acc.items()}
+    cyc = m['GRBM_GUI_ACTIVE']/8
+    print(f.split('/')[1], 'VALU/stream %.0f SALU %.0f LDS %.0f  cycles %.2fM  VALU busy %.0f%%  LDS busy %.0f%%' % (m['SQ_INSTS_VALU']/32768, m['SQ_INSTS_SALU']/32768, m['SQ_INSTS_LDS']/32768, cyc/1e6, 100*m['SQ_ACTIVE_INST_VALU']*4/(1024*cyc), 100*m['SQ_ACTIVE_INST_LDS']/(256*cyc)))
+PY

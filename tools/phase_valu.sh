@@ -14,7 +14,7 @@ for WL in ${WLS:-synth_text corpus:prose corpus:python}; do
   DS="0 65536 131072 256 512 32768 262144 524288"
   [ "$T" = synth_text ] && DS="$DS 8 16 32 288 544 262176"
   for D in $DS; do
-    WL=$WL TAMP_AMD_DBG=$D rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT -o ${T}_d$D -- python tools/prof_phases.py $N > $OUT/${T}_d$D.log 2>&1
+    WL=$WL TAMP_AMD_DBG=$D rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT -o ${T}_d$D -- timeout 200 python tools/prof_phases.py $N > $OUT/${T}_d$D.log 2>&1
   done
 done
 python - <<PY
