@@ -347,7 +347,8 @@ float tamp_amd_last_kernel_ms(void);
 
 /* Releases the device scratch the library keeps between calls on `device` -- decoder window slabs and the split
  * decoder's token-record slab, one set per HIP stream that ever decoded (up to a quarter of the free device memory, 8 GiB
- * at most, per stream).  Synchronises those streams first.  Returns the bytes released or a negative TAMP_AMD_* code.
+ * at most, per stream) -- and the staging buffers of the host-memory batch calls (pinned host memory sized by the largest
+ * output extent ever staged, device chunk buffers).  Synchronises those streams first.  Returns the bytes released or a negative TAMP_AMD_* code.
  * (The library itself falls back to decoders without scratch when an allocation fails; this call is for callers that
  * want the memory back.) */
 long long tamp_amd_trim(int device);

@@ -1142,8 +1142,9 @@ void tamp_amd_set_timing(int enabled) { t_timing = enabled != 0; }
 
 
 // Release the scratch the library keeps between calls on `device` (decoder window slabs, split-decoder records, header
-// pre-pass words: one set per HIP stream that ever decoded; the staging of the host-memory pipeline stays).  Every stream
-// that owns a slab is synchronised first.  Returns the number of bytes released, or a negative TAMP_AMD_* code.
+// pre-pass words: one set per HIP stream that ever decoded) and, since round 4, the staging of the host-memory pipeline
+// (pinned host buffers and device chunk buffers).  Every stream that owns a slab is synchronised first.  Returns the number
+// of bytes released, or a negative TAMP_AMD_* code.
 long long tamp_amd_trim(int device) {
     DeviceCtx* ctx = nullptr;
     int rc = get_ctx(device, &ctx);
@@ -1163,6 +1164,17 @@ long long tamp_amd_trim(int device) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (slab.p) { (void)hipFree(slab.p); freed += (long long)slab.bytes; slab.p = nullptr, slab.bytes = 0; }
         if (slab.split) { (void)hipFree(slab.split); freed += (long long)slab.split_bytes; slab.split = nullptr, slab.split_bytes = 0; }
+    }
+    {   // the host-memory pipeline: pinned staging of non-tiling output slabs (it grows with the largest extent ever staged,
+        // possibly gigabytes of pinned RAM) and the device-side chunk buffers; both grow again on demand
+        std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
+        for (int i = 0; i < DeviceCtx::HostPipe::kDepth; i++) {
+            if (ctx->pipe.s[i] && hipStreamSynchronize(ctx->pipe.s[i]) != hipSuccess) (void)hipGetLastError();
+            auto& st = ctx->pipe.stage[i];
+            if (st.p) { (void)hipHostFree(st.p); freed += (long long)st.bytes; st.p = nullptr, st.bytes = 0; }
+            for (auto* g : {&ctx->pipe.in[i], &ctx->pipe.out[i], &ctx->pipe.meta[i]})
+                if (g->p) { (void)hipFree(g->p); freed += (long long)g->bytes; g->p = nullptr, g->bytes = 0; }
+        }
     }
     return freed;
 }
