@@ -591,9 +591,12 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
                 kind = r & 3u, arg = r >> 10;
                 Vj = nlag ? hpos - lag_before_out(hpos) : hpos;
             }
-#pragma unroll 1
-            for (uint32_t p = p0; p < pend; p++) {
-                const uint32_t m = src[p];
+#pragma unroll
+            for (uint32_t i = 0; i < BPT; i++) {
+                const uint32_t p = p0 + i;
+                if (p >= pend) break;
+                // (four bytes per thread: unrolled, with the marks this thread read before the barrier; sixteen: rolled over LDS)
+                const uint32_t m = BPT <= 4 ? (h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : (uint32_t)src[p];
                 if (m) {  // a token starts here (about five times per 16 bytes: the records sit in L1 / L2)
                     jcur = m - 1, hpos = p;
                     const uint32_t r = rec[jcur];
