@@ -1458,22 +1458,17 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             uint32_t key = (sv & 0x1Fu) ? (((sv & 0x1Fu) << 16) | (W - (uint32_t)bidx[q])) : 0u;
                             const uint32_t key0 = key;
                             bool hit16 = false;  // a 16-byte hit the first pass did not see: a rival for an extended match
-                            {   // wrap zone: every position t = 2..15 bytes before the window's end whose bigram is (x, x)
-                                uint32_t eq = 0;
-#pragma unroll
-                                for (uint32_t jj = 0; jj < 4; jj++) {
-                                    const uint32_t y = lds_u32_unaligned(ebuf, q + W - 16 + 4 * jj) ^ rep;
-                                    uint32_t z = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-                                    z = ~(z | y | 0x7F7F7F7Fu);  // 0x80 in every byte of y that is zero
-                                    eq |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * jj);
-                                }
-                                const uint32_t bg = eq & (eq >> 1);  // bit k: buffer positions q+W-16+k and +k+1 hold x
-                                uint32_t wrapmask = (__builtin_bitreverse32(bg) >> 15) & 0xFFFCu;  // t = 16 - k
+                            {   // wrap zone: the run-interior positions t = 2..15 bytes before the window's end (straight from the
+                                // bitmap of positions the index leaves out: sixteen bits at buffer position q + W - 16) that hold x
+                                const uint32_t wz = q + W - 16, sh = wz & 31u;
+                                uint32_t rb16 = rbits[wz >> 5] >> sh;
+                                if (sh > 16) rb16 |= rbits[(wz >> 5) + 1] << (32u - sh);
+                                uint32_t wrapmask = (__builtin_bitreverse32(rb16) >> 15) & 0xFFFCu;  // bit k <-> t = 16 - k
                                 while (wrapmask) {
                                     const uint32_t t = (uint32_t)__builtin_ctz(wrapmask);
                                     wrapmask &= wrapmask - 1;
                                     const uint32_t c = q + W - t;
-                                    if (!((rbits[c >> 5] >> (c & 31u)) & 1u)) continue;  // indexed: the first pass had it
+                                    if (ebuf[c] != x) continue;  // (the interior of a run of another byte)
                                     const uint32_t i = (e_wp + c) & mask;
                                     if (i == mask) continue;
                                     // (in ring terms such a position is not "four equal bytes": past the newest byte
