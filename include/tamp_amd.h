@@ -107,6 +107,14 @@ const char *tamp_amd_version(void);
 /* Text of the last HIP runtime failure seen by the calling thread ("" if none): what TAMP_AMD_NO_DEVICE meant. */
 const char *tamp_amd_last_error(void);
 
+/* How tamp_batch_compress would launch streams of up to `max_in_len` bytes (0 = unknown) at this window: positions matched
+ * per epoch, LDS bytes per workgroup, threads per workgroup and the workgroups per CU its registers aim at (7 for the
+ * run-aware builds, 6 lean, 5 lazy).  Pure host arithmetic -- no device needed; a diagnostics / capacity-planning call
+ * (the reference has no counterpart: its state is the 16-byte ring + window of compressor.h:13-66).  Returns TAMP_OK or
+ * TAMP_AMD_BAD_ARGUMENT. */
+int tamp_amd_compress_plan(uint8_t window_bits, uint32_t max_in_len, int lazy_matching, uint32_t *block_positions,
+                           uint32_t *lds_bytes, uint32_t *threads, uint32_t *workgroups_per_cu);
+
 /* ---- batch codec ---------------------------------------------------------------------------- */
 
 /*

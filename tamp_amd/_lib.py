@@ -28,6 +28,7 @@ SYMBOLS = (
     "tamp_amd_device_count",
     "tamp_amd_version",
     "tamp_amd_last_error",
+    "tamp_amd_compress_plan",
     "tamp_batch_compress",
     "tamp_batch_decompress",
     "tamp_amd_decoder_state_size",

@@ -1110,6 +1110,25 @@ int tamp_amd_device_count(void) {
 
 const char* tamp_amd_version(void) { return "tamp_amd 0.1 (gfx950)"; }
 
+int tamp_amd_compress_plan(uint8_t window_bits, uint32_t max_in_len, int lazy_matching, uint32_t* block_positions,
+                           uint32_t* lds_bytes, uint32_t* threads, uint32_t* workgroups_per_cu) {
+    if (window_bits < 8 || window_bits > 15) return TAMP_AMD_BAD_ARGUMENT;
+    // (the same decisions as launch_compress: build, block, workgroup size)
+    const uint32_t W = 1u << window_bits;
+    const bool packed = window_bits <= 14, lazy = lazy_matching != 0;
+    const bool long_streams = max_in_len == 0 || align_up(max_in_len, 64) >= 1024;
+    const bool runlist = packed && !lazy && long_streams;
+    const uint32_t blk = pick_block(W, max_in_len, packed, lazy, runlist);
+    const CompressLds L(W, blk, packed, lazy, runlist);
+    const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
+    const uint32_t by_lds = 160u * 1024u / align_up(L.total, 2048u);
+    if (block_positions) *block_positions = blk;
+    if (lds_bytes) *lds_bytes = L.total;
+    if (threads) *threads = blk >= 1024 ? 256u : 64u;
+    if (workgroups_per_cu) *workgroups_per_cu = by_lds < reg_cap ? by_lds : reg_cap;
+    return TAMP_OK;
+}
+
 const char* tamp_amd_last_error(void) { return t_last_error; }
 
 #if defined(TAMP_PROF)
