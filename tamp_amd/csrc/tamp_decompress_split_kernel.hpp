@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
         // (FAST: from the fast loop, where the stage is emptied every four tokens and cannot fill up, and every token has bytes)
         auto put_any = [&](uint32_t kind, uint32_t olen, uint32_t arg, uint32_t written, auto fast_loop) {
             if (!fast_loop.value && olen == 0) return;
-            if (nflushed + nstage >= sa.tokcap) fallback = true;
+            fallback = fallback | (nflushed + nstage >= sa.tokcap);
             rb[nstage++] = kind | (olen << 2) | (arg << 10);
             if (!fast_loop.value && nstage == kParseStage) flush16();
             op += olen;
@@ -273,12 +273,16 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                 uint32_t wl = tok;
                 uint32_t kind = is_lit ? (uint32_t)kRecLit : (uint32_t)kRecCopy;
                 uint32_t arg = is_lit ? (win << 1) >> (32 - lbits) : arg_m;
-                ok = ok && (is_lit ? room >= 1 : (arg_m + tok_m <= W && tok_m <= room));
-                if (!is_lit && (sym == kSymFlush || (extended && sym >= kSymRle))) {
+                {   // (bitwise, not short-circuit: one select instead of a tree of exec-mask regions)
+                    const bool ok_l = room >= 1, ok_m = (arg_m + tok_m <= W) & (tok_m <= room);
+                    ok = ok & (is_lit ? ok_l : ok_m);
+                }
+                const bool special = !is_lit & ((sym == kSymFlush) | (extended & (sym >= kSymRle)));
+                if (special) {
                     // RLE / extended match, decompressor.c:114-273 (FLUSH: left to the exact loop).  Straight-line as well:
                     // windows read from a dry ring are garbage that `ok` discards.
                     Tl += used_m;
-                    const bool have2 = sym != kSymFlush && (Tl >> 3) + 4 <= fill;
+                    const bool have2 = (sym != kSymFlush) & ((Tl >> 3) + 4 <= fill);
                     const uint32_t w2 = window(Tl);
                     const uint32_t trailing = sym == kSymRle ? 4u : 3u;
                     const bool coded2 = (w2 >> 31) != 0;
@@ -294,13 +298,13 @@ __global__ void __launch_bounds__(256) tamp_decode_parse_kernel(SplitArgs sa) {
                     // ... and the reference refills once more in front of the offset if its buffer (25..32 bits after the
                     // top-of-token refill) no longer holds `wbits` bits (decompressor.c:447-456)
                     const uint32_t nb_top = 8 * (((T0 + 24) >> 3) + 1) - T0;
-                    if (!is_rle && nb_top - (Tl - T0) - u < wbits) mark = Tl + u;
+                    mark = (!is_rle & (nb_top - (Tl - T0) - u < wbits)) ? Tl + u : mark;
                     tok = is_rle ? value + 2 : value + minp + 12;
                     wl = is_rle ? min(min(tok, kRleWindowMax), W - wp) : min(tok, W - wp);
                     kind = is_rle ? (uint32_t)kRecFill : (uint32_t)kRecCopyExt;
                     arg = is_rle ? 0u : arg_x;
                     used = is_rle ? u : u + wbits;
-                    ok = have2 && tok <= room && (is_rle || (have3 && arg_x + tok <= W));
+                    ok = have2 & (tok <= room) & (is_rle | (have3 & (arg_x + tok <= W)));
                 }
                 if (ok) {
                     T = Tl + used;
