@@ -120,8 +120,16 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="take roofline.traffic / valu_* from the committed passes instead of profiling a short run now")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="streams timed on the host cores")
-    ap.add_argument("--no-corpus-probe", action="store_true",
-                    help="do not look for enwik8 in the usual places (default run only; see workloads.probe_corpus)")
+    ap.add_argument("--probe-corpus", action="store_true",
+                    help="look for enwik8 in ./ ~/ /data /tmp (plain or .zip); if found it is measured under also.configs2_corpus -- "
+                         "the headline stays configs[1] (only --corpus / $TAMP_CORPUS switch the headline workload)")
+    ap.add_argument("--fetch-corpus", action="store_true",
+                    help="with --probe-corpus: one guarded download attempt of the URL the reference's Makefile uses (rank 0 only)")
+    ap.add_argument("--no-corpus-probe", action="store_true", help=argparse.SUPPRESS)  # (round-4 flag: the probe is opt-in now)
+    ap.add_argument("--corpus-standin", action="store_true",
+                    help="headline workload = the 24,414-stream real-text stand-in for configs[2] (strong scaling over --gpus)")
+    ap.add_argument("--shard-fraction", type=int, default=1,
+                    help="with --corpus-standin on one GPU: time only the first 1/F of the streams (one GPU's share at F GPUs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -157,30 +165,33 @@ def main():
         return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if launched else r)
 
     conf_kw = dict(window=args.window, literal=8, extended=bool(args.extended))
-    # The metric is quoted on enwik8 (BASELINE.json), which neither image holds.  A default run therefore LOOKS for it --
-    # $TAMP_CORPUS, ./enwik8, ~/enwik8, /data, /tmp (plain or .zip), then one guarded download attempt of the URL the
-    # reference's own Makefile uses (15 s at most, rank 0 only, silent on failure) -- and, if it is there, runs configs[2]
-    # on it (every stream checked against the reference C, the whole-file pins) with configs[1] moved to `also`.  What was
-    # tried and what was found is reported as config.corpus_probe either way.
-    corpus_probe = None
-    default_run = args.streams == 65536 and args.stream_len == 4096 and args.window == 10 and args.extended == 1
-    if not args.corpus and default_run and not args.no_corpus_probe and os.environ.get("TAMP_BENCH_NO_PROBE") != "1":
-        found, corpus_probe = wl.probe_corpus(fetch=(rank == 0))
+    # The metric is quoted on enwik8 (BASELINE.json), which neither image holds.  The headline workload NEVER depends on
+    # what happens to lie on the box: it is configs[1] unless --corpus / $TAMP_CORPUS / --corpus-standin
+    # ask for something else.  --probe-corpus (opt-in) looks for the file in the usual places -- no network unless
+    # --fetch-corpus -- and a find is measured under also.configs2_corpus; what was tried is config.corpus_probe.
+    corpus_probe = {"tried": [], "found": None, "fetch": "not attempted",
+                    "note": "opt-in: --probe-corpus [--fetch-corpus] looks for enwik8; --corpus PATH / $TAMP_CORPUS run configs[2] on a file"}
+    probe_found = None
+    if not args.corpus and args.probe_corpus:
+        probe_found, corpus_probe = wl.probe_corpus(env={}, fetch=(args.fetch_corpus and rank == 0))
         if dist is not None:
-            dist.barrier()  # (rank 0 may just have fetched it: everybody looks again, nobody fetches)
-            found, rec2 = wl.probe_corpus(fetch=False)
-            if rank != 0:
-                corpus_probe = rec2
-        if found:
-            args.corpus = found
+            dist.barrier()
     corpus_blob = None
+    standin = bool(args.corpus_standin) and not args.corpus
     if args.corpus:
         corpus_blob = open(args.corpus, "rb").read()
         flat, in_off, in_len = wl.split_fixed(corpus_blob, args.stream_len, keep_tail=True)
         ranges = partition_streams(in_len, world)
+    elif standin:
+        # configs[2]'s shape on the frozen corpora: 24,414 x 4 KiB real-text streams, contiguous ranges balanced by bytes
+        # over the GPUs (strong scaling); --shard-fraction F on one GPU times the first of F such ranges
+        rows = wl.standin_rows(wl.CONFIGS2_STREAMS, args.stream_len)
+        flat = rows.reshape(-1)
+        in_off, in_len = wl.csr_for_fixed(len(rows), args.stream_len)
+        ranges = partition_streams(in_len, world * max(1, args.shard_fraction))[:world] if world == 1 else partition_streams(in_len, world)
     shards = []
     for r in my_shards:
-        if corpus_blob is not None:
+        if corpus_blob is not None or standin:
             b, e = ranges[r]
             lo = int(in_off[b]) if e > b else 0
             hi = int(in_off[e - 1] + in_len[e - 1]) if e > b else 0
@@ -235,7 +246,12 @@ def main():
     alg_bytes = sh0.in_bytes + int(res[0].out_len.to(torch.int64).sum().item())  # in_len + out_len
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
-    if corpus_blob is not None:
+    if standin:
+        workload = (f"configs[2] STAND-IN (enwik8 is not on this box): the distinct 4 KiB chunks of the three frozen corpora "
+                    f"(prose, markup, Python sources) tiled and shuffled to {wl.CONFIGS2_STREAMS} streams, "
+                    f"{'the first 1/%d of them' % args.shard_fraction if args.shard_fraction > 1 else 'all of them'}, window={args.window} "
+                    f"literal=8 extended={args.extended}, contiguous stream ranges balanced by bytes over {world} GPU(s), inputs resident in HBM")
+    elif corpus_blob is not None:
         workload = (f"configs[2]: {os.path.basename(args.corpus)} ({len(corpus_blob)} B) cut into {job_streams} independent "
                     f"streams of {args.stream_len} B (short tail kept as the last stream), window={args.window} literal=8 "
                     f"extended={args.extended}, contiguous stream ranges balanced by bytes over {world} GPU(s), inputs resident in HBM")
@@ -251,11 +267,11 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if corpus_blob is not None else "weak",
+        "scaling": "strong" if (corpus_blob is not None or standin) else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": ("real: " + os.path.basename(args.corpus) + " sha256=" + hashlib.sha256(corpus_blob).hexdigest()[:16])
-                if corpus_blob is not None else "synthetic",
+                if corpus_blob is not None else ("real text: frozen corpora of tests/golden (stand-in for enwik8)" if standin else "synthetic"),
         "config": {
             "workload": workload,
             "streams_total": job_streams,
@@ -287,7 +303,7 @@ def main():
         },
     }
     traffic, src = pmc_traffic_bytes()
-    if corpus_blob is None and args.streams == 65536 and args.stream_len == 4096:
+    if corpus_blob is None and not standin and args.streams == 65536 and args.stream_len == 4096:
         result["roofline"]["traffic"] = traffic
         result["roofline"]["traffic_source"] = src
         # the real limiter (SURVEY.md 8d's secondary counters): the kernel is bound by VALU issue, not by HBM
@@ -309,13 +325,7 @@ def main():
             result["corpus_pins"] = corpus_pins(args, corpus_blob, torch, np)
         except Exception as e:
             result["corpus_pins"] = {"error": repr(e)[:200]}
-        if corpus_probe is not None and world == 1:
-            # the corpus was found by the probe, not asked for: configs[1] (the synthetic batch) moves here
-            try:
-                result["also"] = {"configs1_synthetic": also_configs1(args, torch, np, conf_kw)}
-            except Exception as e:  # noqa: BLE001
-                result["also"] = {"configs1_synthetic": {"error": repr(e)[:200]}}
-    if extras and world == 1 and corpus_blob is None:
+    if extras and world == 1 and corpus_blob is None and not standin:
         # Not part of the metric (informational, each guarded): the v1 format, the decode of what was just produced,
         # and real text found on this machine next to the synthetic headline.
         also = {}
@@ -331,6 +341,15 @@ def main():
                 if isinstance(v, dict) and "extended_GBps" in v}
         except Exception as e:
             also["real_text"] = {"error": repr(e)[:200]}
+        try:
+            also["strong_scaling_standin"] = also_strong_scaling(args, torch, np)
+        except Exception as e:  # noqa: BLE001
+            also["strong_scaling_standin"] = {"error": repr(e)[:200]}
+        if probe_found:
+            try:
+                also["configs2_corpus"] = also_corpus(args, probe_found, torch, np)
+            except Exception as e:  # noqa: BLE001
+                also["configs2_corpus"] = {"error": repr(e)[:200]}
         try:
             also["baseline_configs"] = also_baseline_configs(torch, np)
         except Exception as e:  # noqa: BLE001 -- the headline line must not die for a side measurement
@@ -361,6 +380,82 @@ def also_configs1(args, torch, np, conf_kw, steps=10, warmup=3):
             "all_streams_ok": bool((res.status == 0).all().item())}
 
 
+def also_strong_scaling(args, torch, np, reps=5):
+    """Strong scaling of BASELINE configs[2] PREDICTED on one device: the 24,414-stream real-text
+    stand-in is cut into N contiguous ranges balanced by bytes -- what `bench.py --corpus-standin --gpus N` gives each GPU
+    -- and every range is timed alone on this device; predicted_speedup_at_N = t(all 24,414) / max over the N ranges.
+    It leaves out what only a second device can show (host launch overlap: 31 us per shard)."""
+    import tamp_amd
+    from tamp_amd import partition_streams
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda", 0)
+    L = 4096
+    rows = wl.standin_rows(wl.CONFIGS2_STREAMS, L)
+    off, ln = wl.csr_for_fixed(len(rows), L)
+    data = torch.from_numpy(rows.reshape(-1)).to(dev)
+    off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+    len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
+
+    def timed(b, e):
+        ms = []
+        o = off_t[b:e] - off_t[b]
+        d = data[int(off[b]): int(off[e - 1] + ln[e - 1])]
+        for _ in range(reps + 1):
+            r = tamp_amd.compress_batch(d, o, len_t[b:e], max_in_len=L, timing=True, window=args.window, literal=8,
+                                        extended=bool(args.extended))
+            ms.append(float(r.kernel_ms))
+        return float(np.median(ms[1:]))
+
+    out = {"streams": len(rows), "stream_len": L, "scaling": "strong (fixed total work: 24,414 streams over N GPUs)",
+           "timing": f"kernel time (hipEvents), median of {reps} launches per range, one device"}
+    t_all = timed(0, len(rows))
+    out["t_ms_all"] = round(t_all, 4)
+    out["input_GBps_all"] = round(len(rows) * L / (t_all * 1e-3) / 1e9, 2)
+    for N in (2, 4, 8):
+        ts = [timed(b, e) for (b, e) in partition_streams(ln, N)]
+        out[f"t_ms_shards_at_{N}"] = [round(t, 4) for t in ts]
+        out[f"predicted_speedup_at_{N}"] = round(t_all / max(ts), 3)
+    return out
+
+
+def also_corpus(args, path, torch, np):
+    """A corpus the opt-in probe found (enwik8): configs[2] on one device as a SIDE measurement -- cut into 4 KiB streams
+    (short tail kept), kernel-timed, the first 2,048 streams checked against the reference C, whole-file pins when the
+    file has enwik8's length."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    blob = open(path, "rb").read()
+    flat, off, ln = wl.split_fixed(blob, 4096, keep_tail=True)
+    dev = torch.device("cuda", 0)
+    data = torch.from_numpy(np.ascontiguousarray(flat)).to(dev)
+    off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+    len_t = torch.from_numpy(ln.astype(np.int32)).to(dev)
+    out = {"file": os.path.basename(path), "bytes": len(blob), "streams": int(len(ln)), "sha256": hashlib.sha256(blob).hexdigest()[:16]}
+    kind, impl = _checker()
+    for ext in (True, False):
+        ms, r = [], None
+        for _ in range(4):
+            r = tamp_amd.compress_batch(data, off_t, len_t, max_in_len=4096, timing=True, window=args.window, literal=8, extended=ext)
+            ms.append(float(r.kernel_ms))
+        k = min(2048, len(ln))
+        want = impl.compress_batch(flat[: int(off[k - 1] + ln[k - 1])], off[:k], ln[:k], threads=host_threads()[0],
+                                   window=args.window, literal=8, extended=ext)
+        olen, ooff = r.out_len[:k].cpu().numpy(), r.out_off[:k].cpu().numpy()
+        gout = r.out[: int(ooff[-1] + olen[-1])].cpu().numpy()
+        ok = all(gout[ooff[i]: ooff[i] + olen[i]].tobytes() == want.stream(i) for i in range(k))
+        tag = "extended" if ext else "v1"
+        out[tag] = {"kernel_ms": round(min(ms[1:]), 4), "input_GBps": round(len(blob) / (min(ms[1:]) * 1e-3) / 1e9, 2),
+                    "ratio": round(float(r.out_len.to(torch.int64).sum().item()) / len(blob), 4),
+                    "parity": ("bit-exact" if ok else "MISMATCH") + f" (first {k} streams vs {kind})"}
+    try:
+        out["corpus_pins"] = corpus_pins(args, blob, torch, np)
+    except Exception as e:  # noqa: BLE001
+        out["corpus_pins"] = {"error": repr(e)[:200]}
+    return out
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the compress kernel from the committed rocprofv3 PMC summaries of this command (bench.py
     cannot run the profiler on itself); (None, reason) if they are missing."""
@@ -384,6 +479,17 @@ def pmc_traffic_bytes():
     return None, "no committed PMC pass"
 
 
+#: Cycles of its SIMD's issue time one wave64 VALU instruction costs, MEASURED (tools/probe/valu_issue_probe.hip ->
+#: profiles/r5_valu_issue_probe.txt, seven wavefronts per SIMD): 4.08-4.13 for every integer class this kernel leans on
+#: (v_and/v_lshl with a scalar operand, v_alignbyte, v_bfe, v_cmp, v_cndmask, v_min/v_max, v_mul, every three-operand
+#: form, DPP moves); only plain VOP1/VOP2 and/or/xor/add/sub/lshr/mov on VGPR or constant operands pair up across waves
+#: (2.2), and interleaved with the others they measured 3.7.  4 is the round figure the ceiling is quoted with.
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 4.0
+ISSUE_MODEL = ("measured: 4.1 cycles of SIMD issue time per wave64 integer VALU instruction (2.2 only for plain VGPR/constant "
+               "VOP1/VOP2 and/or/xor/add/sub/lshr/mov pairing up across waves; 3.7 interleaved), SALU overlaps with VALU of other "
+               "waves -- tools/probe/valu_issue_probe.hip, profiles/r5_valu_issue_probe.txt")
+
+
 def live_pmc(args, in_bytes):
     """HBM bytes and VALU figures of the compress kernel from rocprofv3 --pmc passes run NOW over `bench.py --steps 2
     --warmup 1 --no-cpu-baseline --no-live-pmc` (FETCH_SIZE, WRITE_SIZE and the SQ group each in a pass of their own, with
@@ -398,7 +504,6 @@ def live_pmc(args, in_bytes):
     if not os.path.exists(exe):
         return {}
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc",
-           "--no-corpus-probe",
            "--streams", str(args.streams), "--stream-len", str(args.stream_len), "--window", str(args.window),
            "--extended", str(args.extended)]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -433,8 +538,9 @@ def live_pmc(args, in_bytes):
         "valu_per_stream": round(got["SQ_INSTS_VALU"] / args.streams),
         "salu_per_stream": round(got.get("SQ_INSTS_SALU", 0) / args.streams),
         "valu_busy": round(got["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 3),
-        "issue_ceiling_GBps": round(in_bytes / (got["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9)) / 1e9, 1),
+        "issue_ceiling_GBps": round(in_bytes / (got["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE_INSTRUCTION / (1024 * 2.4e9)) / 1e9, 1),
         "issue_source": "measured in this run (SQ pass above)",
+        "issue_model": ISSUE_MODEL,
         "live_pmc_seconds": round(time.perf_counter() - t0, 1),
     }
 
@@ -465,7 +571,8 @@ def pmc_issue_figures(n_streams, in_bytes):
             "valu_per_stream": round(valu / n_streams),
             "salu_per_stream": round(m.get("SQ_INSTS_SALU", 0) / n_streams),
             "valu_busy": round(m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cycles), 3),
-            "issue_ceiling_GBps": round(in_bytes / (valu * 4 / (1024 * clock_ghz * 1e9)) / 1e9, 1),
+            "issue_ceiling_GBps": round(in_bytes / (valu * VALU_CYCLES_PER_WAVE_INSTRUCTION / (1024 * clock_ghz * 1e9)) / 1e9, 1),
+            "issue_model": ISSUE_MODEL,
             "issue_source": f"profiles/{tag}_pmc_sq{{,2}}_counter_collection.csv"
                             + ("" if tag == PROFILE_TAG else " [STALE: captured on an earlier build of the kernel]"),
         }

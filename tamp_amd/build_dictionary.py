@@ -272,6 +272,8 @@ def build_dictionary_cli(input, output="dictionary.bin", *, window=10, literal=8
     GPU evaluation (tests).  -> a summary dict."""
     log = log if log is not None else (lambda *a: print(*a, file=sys.stderr))
     corpus = read_corpus(input, delimiter)
+    if not corpus:
+        raise ValueError(f"No samples in {input}")
     W = 1 << window
     total = total if total is not None else gpu_total(corpus, window, literal, extended)
     swept = trim_threshold is None
@@ -286,6 +288,8 @@ def build_dictionary_cli(input, output="dictionary.bin", *, window=10, literal=8
     baseline = total(None)
     knee = find_knee([(0, baseline)] + points) if points[0][0] else points[0][0]
     pick = min((p[0] for p in points), key=lambda s: abs(s - int(W * target_fill))) if target_fill is not None else knee
+    if pick <= 0:  # (no step of the table qualifies as the knee: the smallest tabulated size is the selection)
+        pick = points[0][0]
     raw = sum(len(s) for s in corpus)
     if not quiet:
         log(f"\nDictionary analysis (window={window}, {W} bytes):")
@@ -302,6 +306,10 @@ def build_dictionary_cli(input, output="dictionary.bin", *, window=10, literal=8
         d2, eff2 = build(corpus, window, literal, extended, trim_threshold, fill)
         if eff2:
             full, eff = d2, eff2
+        else:
+            # nothing fits the requested capacity (a target fill below the shortest entry): write the smallest tabulated
+            # size of the full build rather than, silently, ALL of it
+            eff = min(eff, points[0][0])
     Path(output).write_bytes(bytes(full[W - eff :]))
     final = total(full)
     if not quiet:

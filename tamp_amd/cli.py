@@ -101,7 +101,7 @@ def main(argv=None) -> int:
             return 2
         try:
             bd.build_dictionary_cli(args.input, args.output, window=args.window, literal=args.literal, extended=args.extended,
-                                    delimiter=args.delimiter.encode().decode("unicode_escape"), trim_threshold=args.trim_threshold,
+                                    delimiter=args.delimiter, trim_threshold=args.trim_threshold,
                                     target_fill=args.target_fill, quiet=args.quiet)
         except ValueError as e:
             print(f"tamp_amd: {type(e).__name__}: {e}", file=sys.stderr)

@@ -218,6 +218,8 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
         uint32_t best = 1024;
         for (uint32_t b = 1280; b <= 2048; b += 256)
             if (b <= blk && per_cu(b) == want) best = b;
+        // (the stream's own length: one epoch instead of two for streams a little over 1 KiB, when that costs no workgroup)
+        if (blk > best && blk < 2048 && per_cu(blk) == want) best = blk;
         blk = best;
     }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
@@ -287,7 +289,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
         return TAMP_AMD_BAD_ARGUMENT;
     }
-    const uint32_t threads = a.blk >= 1024 ? 256 : 64;
+    const uint32_t threads = (a.blk >= 1024 || (long_streams && a.blk >= 512 && getenv("TAMP_AMD_BLK"))) ? 256 : 64;  // (tuning: smaller blocks for long streams)
     const uint32_t grid = (uint32_t)(n_streams < (1u << 20) ? n_streams : (1u << 20));
     // the six builds: lazy (u32 / u16 entries), run-aware (generic window / 2^10 with the scan constants as immediates),
     // lean one-wavefront build for short messages (512 buckets: a quarter of the cursors to zero and scan per message),
@@ -543,7 +545,10 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         sa.d = a;
         // resolve: a workgroup per stream, or -- short messages, out_cap up to 1 KiB -- a wavefront per stream, four per workgroup
         bool wave_resolve = max_out_cap <= kSplitWaveMaxOut;
-        if (const char* e = getenv("TAMP_AMD_SPLIT_WAVE_MAX")) wave_resolve = max_out_cap <= (uint32_t)atoi(e);  // (tuning)
+        if (const char* e = getenv("TAMP_AMD_SPLIT_WAVE_MAX")) {  // (tuning; the one-wavefront RESOLVE covers 4 x 16 x 64 = 4,096 positions)
+            const int v = atoi(e);
+            wave_resolve = max_out_cap <= (uint32_t)(v < 0 ? 0 : (v > 4096 ? 4096 : v));
+        }
         const uint32_t lds = split_resolve_lds(max_out_cap) * (wave_resolve ? 4u : 1u);
         auto resolve_kernel = wave_resolve ? tamp_decode_resolve_kernel<64, 4> : tamp_decode_resolve_kernel<256, 4>;
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_kernel),

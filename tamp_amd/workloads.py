@@ -155,7 +155,7 @@ CORPUS_PROBE_DIRS = (".", "~", "/data", "/tmp", "~/datasets", "./datasets")
 ENWIK8_URL = "https://mattmahoney.net/dc/enwik8.zip"
 
 
-def probe_corpus(env=None, dirs=None, fetch=True, fetch_to="/tmp", timeout_s: float = 15.0, want_len: int = ENWIK8_PINS["len"]):
+def probe_corpus(env=None, dirs=None, fetch=False, fetch_to="/tmp", timeout_s: float = 15.0, want_len: int = ENWIK8_PINS["len"]):
     """Look for enwik8 (plain file or ``enwik8.zip``) without being told where: ``$TAMP_CORPUS``, then CORPUS_PROBE_DIRS,
     then ONE guarded download attempt of ENWIK8_URL (``timeout_s`` seconds in all; any failure is silent -- the build
     and GPU boxes have no network).  A candidate counts only if it holds exactly ``want_len`` bytes.  A zip is unpacked
@@ -258,6 +258,29 @@ def split_fixed(blob, chunk: int = 4096, keep_tail: bool = True):
     else:
         flat = flat[: n_full * chunk]
     return flat, in_off, in_len
+
+
+#: streams of BASELINE configs[2] (enwik8 cut into 4 KiB pieces: 24,414 full ones; the 576-byte tail aside)
+CONFIGS2_STREAMS = 24_414
+
+
+def standin_rows(n_streams: int = CONFIGS2_STREAMS, chunk: int = 4096, seed: int = 2) -> np.ndarray:
+    """Stand-in for BASELINE configs[2] while enwik8 is out of reach: every distinct 4 KiB chunk of the three frozen
+    corpora (prose, markup, Python sources), tiled to ``n_streams`` rows and shuffled with a fixed seed -- a real-text
+    batch of the metric's own shape (24,414 streams) whose costs are as uneven as real text makes them."""
+    parts = []
+    for name in ("prose", "markup", "python"):
+        flat = np.frombuffer(real_text(name, frozen_only=True), dtype=np.uint8)
+        k = flat.size // chunk
+        if k:
+            parts.append(flat[: k * chunk].reshape(k, chunk))
+    if not parts:
+        raise ValueError("the frozen corpora (tests/golden/corpus_*.txt.xz) are not next to this package")
+    base = np.concatenate(parts)
+    rng = np.random.default_rng(seed)
+    reps = (n_streams + len(base) - 1) // len(base)
+    idx = np.concatenate([rng.permutation(len(base)) for _ in range(reps)])[:n_streams]  # every chunk equally often
+    return np.ascontiguousarray(base[idx])
 
 
 def tile_rows(blob, n_streams: int, chunk: int = 4096) -> np.ndarray:

@@ -46,7 +46,7 @@ def test_eight_full_size_shards_one_process_as_invoked():
     assert line["scaling"] == "weak" and "configs[1]" in cfg["workload"]
     assert line["ms_per_step"] <= 1.03 * cfg["sum_kernel_ms_per_step"], (line["ms_per_step"], cfg)
     assert 0 < cfg["host_launch_us_per_shard"] < 300, cfg
-    assert cfg["corpus_probe"]["found"] is None  # (a default run looks for enwik8 and says so; none on this box)
+    assert cfg["corpus_probe"]["found"] is None and cfg["corpus_probe"]["tried"] == []  # (the probe is opt-in: --probe-corpus)
 
 
 def test_eight_full_size_shards_keep_their_own_slabs_and_bytes(ta, checker):
@@ -146,14 +146,29 @@ def test_markup_corpus_matches_reference(ta, checker):
     assert g1.stream(0) == w1.stream(0)
 
 
-def test_bench_default_run_reports_its_corpus_probe(tmp_path):
-    """A default `python bench.py` looks for enwik8 and says what it tried (config.corpus_probe); with a file of the right
-    length under $TAMP_CORPUS it would switch to configs[2] -- exercised here through --corpus on a small file so that the
-    test stays short, and through the probe record of a run that finds nothing."""
+def test_bench_corpus_probe_is_opt_in(tmp_path):
+    """a default `python bench.py` neither looks for enwik8 nor touches the network -- its headline is
+    configs[1] whatever lies on the box; `--probe-corpus` (no download without --fetch-corpus) says what it tried in
+    config.corpus_probe, and a find would be measured under also.configs2_corpus without changing the headline."""
     line = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
     probe = line["config"]["corpus_probe"]
-    assert probe is not None and probe["found"] is None and any(t.endswith("/enwik8") for t in probe["tried"])
+    assert probe["found"] is None and probe["tried"] == [] and probe["fetch"] == "not attempted"
+    assert "configs[1]" in line["config"]["workload"] and line["scaling"] == "weak"
+    line = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--probe-corpus"], {})
+    probe = line["config"]["corpus_probe"]
+    assert probe["found"] is None and any(t.endswith("/enwik8") for t in probe["tried"]) and probe["fetch"] == "not attempted"
     assert "configs[1]" in line["config"]["workload"]
+
+
+def test_bench_strong_scaling_standin_as_invoked():
+    """`bench.py --corpus-standin [--shard-fraction F]` runs configs[2]'s shape (24,414 x 4 KiB of
+    real text, strong scaling) on the frozen corpora; one GPU's share at 8 GPUs (3,052 streams) is timed as invoked."""
+    whole = _bench(["--corpus-standin", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], {})
+    assert whole["scaling"] == "strong" and whole["config"]["streams_total"] == 24414 and whole["config"]["all_streams_ok"]
+    assert "STAND-IN" in whole["config"]["workload"]
+    part = _bench(["--corpus-standin", "--shard-fraction", "8", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], {})
+    assert 3040 <= part["config"]["streams_total"] <= 3064 and part["config"]["all_streams_ok"]
+    assert part["ms_per_step"] < whole["ms_per_step"] / 4  # (an eighth of the work: well under a quarter of the time)
 
 
 def test_build_dictionary_cli_end_to_end(tmp_path, ta):

@@ -302,6 +302,48 @@ def test_corpus_probe_finds_plain_and_zipped_files_and_reports_what_it_tried(tmp
     assert all(not d.startswith("/root/reference") for d in wl.CORPUS_PROBE_DIRS)  # (never read at run time)
 
 
+def test_round5_advice_items(tmp_path):
+    """the corpus probe never fetches unless told to; a build-dictionary delimiter is taken verbatim as the
+    reference does (tamp/cli/build_dictionary.py:696-699: `content.split(delimiter.encode())`), an empty corpus is an
+    error, and a selection that fits nothing falls back to the SMALLEST tabulated size, not the full dictionary."""
+    import inspect
+
+    from tamp_amd import build_dictionary as bd, workloads as wl
+
+    assert inspect.signature(wl.probe_corpus).parameters["fetch"].default is False
+    src = tmp_path / "m.txt"
+    src.write_bytes("aé1éb\\nc".encode())
+    assert bd.read_corpus(src, "é") == [b"a", b"1", "b\\nc".encode()]
+    assert bd.read_corpus(src, "\\n") == ["aé1éb".encode(), b"c"]  # a literal backslash-n is two bytes, not a newline
+    (tmp_path / "empty.txt").write_bytes(b"\n\n")
+    with pytest.raises(ValueError):
+        bd.build_dictionary_cli(tmp_path / "empty.txt", tmp_path / "d.bin", window=8, literal=7, total=lambda d: 0, quiet=True)
+    # a target fill below anything the miner can place: the smallest tabulated size is written and marked
+    corpus = [b'{"id":"dev-%05d","ok":true}' % i for i in range(200)]
+    (tmp_path / "c.txt").write_bytes(b"\n".join(corpus))
+    lines = []
+    res = bd.build_dictionary_cli(tmp_path / "c.txt", tmp_path / "d.bin", window=8, literal=7, trim_threshold=4, target_fill=0.004,
+                                  total=lambda d: 1000 if d is None else 1000 - sum(1 for b in d[-64:] if b in b'{"id:dev-ok,true}'),
+                                  log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert 0 < res["dictionary_bytes"] <= res["tradeoff"][0][0] and any("<-- selected" in x for x in lines)
+    assert len((tmp_path / "d.bin").read_bytes()) == res["dictionary_bytes"]
+
+
+def test_standin_rows_for_configs2_are_frozen():
+    """The stand-in for BASELINE configs[2] (enwik8 is out of reach): 24,414 x 4 KiB rows drawn from the three frozen
+    corpora with a fixed seed -- the same rows on every box, all three corpora present."""
+    from tamp_amd import workloads as wl
+
+    a, b = wl.standin_rows(512), wl.standin_rows(512)
+    assert a.shape == (512, 4096) and a.dtype == np.uint8 and np.array_equal(a, b)
+    assert wl.CONFIGS2_STREAMS == 24414
+    chunks = {bytes(r[:64]) for r in a}
+    for name in ("prose", "markup", "python"):
+        flat = wl.real_text(name, frozen_only=True)
+        heads = {flat[i * 4096: i * 4096 + 64] for i in range(len(flat) // 4096)}
+        assert chunks & heads, name
+
+
 def test_build_dictionary_pipeline_with_a_cpu_evaluator(tmp_path, oracle):
     """`python -m tamp_amd build-dictionary` (tamp/cli/build_dictionary.py:706-927): the mining, packing,
     tradeoff table and knee on a corpus of 600 telemetry messages, with the whole-corpus evaluation -- one GPU batch launch

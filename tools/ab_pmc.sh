@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box comparison of library variants (tamp_amd/libtamp_var<X>.so): kernel time (tools/ab_bench.py) and, per variant,
 # one rocprofv3 --pmc pass with the instruction counters.   usage: VARS="0 1 2" bash tools/ab_pmc.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for v in $VARS; do TAMP_VAR=$v python tools/ab_bench.py 2>&1 | grep -v amdgpu.ids; done
 for v in $VARS; do
   OUT=gpurun_out/abpmc_$v; rm -rf $OUT; mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of library variants.  usage: VARS="0 5" bash tools/ab_traffic.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for v in $VARS; do
   for c in FETCH_SIZE WRITE_SIZE; do
     OUT=gpurun_out/abtr_${v}_$c; rm -rf $OUT; mkdir -p $OUT

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 WL=telemetry SLEN=256 WINDOW=8 LITERAL=7 TELDICT=1 python tools/prof_phases.py 65536 2>&1 | grep -v amdgpu
 OUT=gpurun_out/c5pmc; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq -- python tools/config5.py 1048576 > $OUT/log 2>&1

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 OUT=gpurun_out/decpmc; rm -rf $OUT; mkdir -p $OUT
 cat > /tmp/dec_one.py <<'PY'
 import sys, os

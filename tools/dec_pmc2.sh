@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction counters of the lane-per-stream decoders on the bench batch, extended and v1 format.  usage: bash tools/dec_pmc2.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 cat > /tmp/dec_one.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 cat > /tmp/dec_sp.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # RESOLVE kernel truncated after a phase (libtamp_vars<k>.so built with -DTAMP_SPLIT_STOP=k): time and instruction counts per phase.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 cat > /tmp/dec_spv.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))

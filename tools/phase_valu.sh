@@ -5,7 +5,7 @@
 # all streams; the truncating bits (8 / 16 / 32: return behind load / index / match + jump tables of the FIRST epoch)
 # give the prologue and the first epoch's query set-up.  Writes gpurun_out/phase_valu/phase_valu.csv
 #   usage (GPU box, repo root): [WLS="synth_text corpus:prose corpus:python"] [N=8192] bash tools/phase_valu.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 OUT=gpurun_out/phase_valu; rm -rf $OUT; mkdir -p $OUT
 N=${N:-8192}
 for WL in ${WLS:-synth_text corpus:prose corpus:python}; do

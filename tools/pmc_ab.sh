@@ -1,11 +1,11 @@
 # usage: bash tools/pmc_ab.sh TAG "corpus ext encoder" ...   -> profiles/ab/<TAG>_<corpus>_<ext>_<encoder>_{sq}.csv + summary line
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 TAG=$1; shift
 mkdir -p gpurun_out/ab
 for cfg in "$@"; do set -- $cfg
 OUT=gpurun_out/ab/${TAG}_$1_$2_$3; rm -rf $OUT; mkdir -p $OUT
-CORPUS=$1 EXT=$2 TAMP_AMD_ENCODER=$3 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq -- python tools/one_corpus.py 32768 2>&1 | grep "GB/s"
-CORPUS=$1 EXT=$2 TAMP_AMD_ENCODER=$3 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT -o sq2 -- python tools/one_corpus.py 32768 2>&1 | grep -c "GB/s" > /dev/null
+CORPUS=$1 EXT=$2 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq -- python tools/one_corpus.py 32768 2>&1 | grep "GB/s"
+CORPUS=$1 EXT=$2 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT -o sq2 -- python tools/one_corpus.py 32768 2>&1 | grep -c "GB/s" > /dev/null
 done
 python - <<'PY'
 import csv, glob, collections

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for cfg in "prose 1 1" "prose 0 0" "python 1 1" "synth 1 0"; do set -- $cfg
 OUT=gpurun_out/pmc_one_$1_$2; rm -rf $OUT; mkdir -p $OUT
 CORPUS=$1 EXT=$2 RUNS=$3 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq -- python tools/one_corpus.py 32768 2>&1 | grep "GB/s"

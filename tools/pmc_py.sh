@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for D in 0 16384 2 1; do
 OUT=gpurun_out/pmc_py_$D; rm -rf $OUT; mkdir -p $OUT
 TAMP_AMD_DBG=$D WL="glob:/usr/lib/python3.10/*.py" rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python tools/prof_phases.py 8192 > $OUT/log 2>&1

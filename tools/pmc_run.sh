@@ -2,7 +2,7 @@
 # rocprofv3 evidence (rounds 2-3).  Separate passes: kernel-trace/stats alone; each --pmc group alone (FETCH_SIZE and WRITE_SIZE
 # do not fit into one pass).  Summaries land in gpurun_out/pmc_$TAG; copy what is to be tracked into profiles/.
 #   usage (GPU box, repo root): TAG=r2a bash tools/pmc_run.sh
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 TAG=${TAG:-r4}
 OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err

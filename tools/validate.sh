@@ -4,7 +4,7 @@
 #                                                      batch kernels, pieces, streaming scripts, both resume kernels, static grid
 #   TAG=r4 bash tools/validate.sh final                GPU test tier, smoke(), then the rocprofv3 passes of tools/pmc_run.sh
 # (one maintained script instead of the per-round one-offs of rounds 1-3)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 MODE=${1:-fuzz}
 if [ "$MODE" = fuzz ]; then
   S=${SEED:-50}; K=${SCALE:-1}; OUT=gpurun_out/fuzz_$S; mkdir -p $OUT
