@@ -210,8 +210,30 @@ class TextCompressor(Compressor):
         return super().write(data.encode())
 
 
+#: one-shot ``compress()`` calls of at least this many bytes in the v1 format go to the batch call as ONE stream, which
+#: spreads its blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>; csrc/tamp_capi.hip launch_compress_blocks)
+ONE_SHOT_BLOCK_MIN = 256 << 10
+
+
 def compress(data: Union[bytes, str], *args, **kwargs) -> bytes:
     """``tamp.compress`` (tamp/_c_compressor.pyx:189-199)."""
+    if (not args and isinstance(data, (bytes, bytearray, memoryview)) and len(data) >= ONE_SHOT_BLOCK_MIN
+            and kwargs.get("extended", True) is False and kwargs.get("literal", 8) == 8
+            and not kwargs.get("lazy_matching") and not kwargs.get("dictionary_reset") and not kwargs.get("append")
+            and set(kwargs) <= {"window", "literal", "dictionary", "extended", "lazy_matching", "dictionary_reset", "append", "device"}):
+        # the same bytes as Compressor(...).write(data) + flush(write_token=False): the batch contract (DESIGN.md section 1)
+        from .batch import compress_batch
+
+        window, dictionary = kwargs.get("window", 10), kwargs.get("dictionary")
+        if dictionary is not None and len(dictionary) != (1 << window):
+            raise ValueError("Dictionary-window size mismatch.")
+        if not 8 <= window <= 15:
+            raise ValueError
+        r = compress_batch([bytes(data)], window=window, literal=8, extended=False, dictionary=dictionary,
+                           device=kwargs.get("device", 0))
+        if int(r.status[0]) != _lib.OK:
+            _raise_for(int(r.status[0]))
+        return r.stream(0)
     with BytesIO() as f:
         c = TextCompressor(f, *args, **kwargs) if isinstance(data, str) else Compressor(f, *args, **kwargs)
         c.write(data)

@@ -92,6 +92,10 @@ struct DeviceCtx {
             }
         } stage[kDepth];
     } pipe;
+    // block mode (one long v1 stream over all workgroups): per-block tables of pass 1 / positions of pass 2, and the four
+    // table words of the stream read back before the launch
+    std::mutex blk_mu;
+    HostPipe::Grow blk_scratch;
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -228,6 +232,91 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     return blk;
 }
 
+// Block mode, pass 2: entry offset and bit position of every block, one serial walk over the tables of pass 1 (a dependent
+// LDS read per block: ~4 ms for the 97,657 blocks of a 100 MB stream).  One workgroup; 512 blocks' tables per round.
+__global__ void __launch_bounds__(256) tamp_block_scan_kernel(const uint32_t* table, unsigned long long* info, uint32_t n_blocks,
+                                                              uint32_t lead_bits) {
+    constexpr uint32_t kRound = 512;
+    __shared__ uint32_t t[kRound * 16];
+    __shared__ unsigned long long res[kRound];
+    __shared__ unsigned long long carry_bp;
+    __shared__ uint32_t carry_entry;
+    if (threadIdx.x == 0) carry_bp = lead_bits, carry_entry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += kRound) {
+        const uint32_t cnt = n_blocks - b0 < kRound ? n_blocks - b0 : kRound;
+        for (uint32_t i = threadIdx.x; i < cnt * 16; i += blockDim.x) t[i] = table[(size_t)b0 * 16 + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long bp = carry_bp;
+            uint32_t entry = carry_entry;
+            for (uint32_t i = 0; i < cnt; i++) {
+                res[i] = (bp << 4) | entry;
+                const uint32_t v = t[i * 16 + entry];
+                entry = v & 15u;
+                bp += v >> 4;
+            }
+            carry_bp = bp, carry_entry = entry;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) info[b0 + i] = res[i];
+        __syncthreads();
+    }
+}
+
+// Block mode (tamp_compress_kernel<.., BLOCKM>): ONE long stream of the v1 format, literal 8, default parse, fresh window.
+// -> TAMP_OK when the stream was taken this way, 1 when the call does not qualify (the caller goes on with the batch kernel).
+int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* conf, uint32_t max_in_len, hipStream_t st) {
+    const uint32_t W = 1u << conf->window;
+    uint32_t min_len = 256u << 10;
+    if (const char* e = getenv("TAMP_AMD_BLOCK_MIN")) min_len = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;  // (tuning / tests; 0 = off)
+    if (conf->extended || conf->lazy_matching || conf->literal != 8 || conf->window > 14 || a.state || a.seg_flags || max_in_len < min_len)
+        return 1;
+    std::lock_guard<std::mutex> lock(ctx->blk_mu);
+    // the stream's table row: length, capacity (the launch geometry and the zero fill depend on them)
+    struct Row { uint64_t in_off, out_off; uint32_t in_len, out_cap; } row;
+    HIP_OK(hipMemcpyAsync(&row.in_off, a.in_off, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&row.out_off, a.out_off, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&row.in_len, a.in_len, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&row.out_cap, a.out_cap, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const uint32_t n = row.in_len;
+    if (n < min_len) return 1;
+    a.blk = pick_block(W, 0, true, false, false);
+    if (a.blk > 1024) a.blk = 1024;  // (more, smaller blocks: the unit of parallelism here)
+    const CompressLds L(W, a.blk, true, false, false);
+    if (L.total > ctx->lds_per_block) return 1;
+    const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
+    const size_t table_bytes = (size_t)n_blocks * 16 * 4, info_bytes = (size_t)n_blocks * 8;
+    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + 256));
+    a.blk_table = static_cast<uint32_t*>(ctx->blk_scratch.p);
+    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + ((table_bytes + 255) & ~(size_t)255));
+    a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
+    auto kernel = tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+    int per_cu = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, L.total));
+    if (per_cu < 1) per_cu = 1;
+    const uint32_t g = (uint32_t)std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, n_blocks);
+    timing_begin(st);
+    // every byte the emitters may OR into: header + 9 bits per input byte at most (all literals), capped by the caller's room
+    const uint64_t bound = (uint64_t)a.nlead + ((uint64_t)n * 9 + 7) / 8 + 8;
+    HIP_OK(hipMemsetAsync(a.out + row.out_off, 0, (size_t)std::min<uint64_t>(bound, row.out_cap), st));
+    for (uint32_t pass = 1; pass <= 3; pass++) {
+        if (pass == 2) {
+            hipLaunchKernelGGL(tamp_block_scan_kernel, dim3(1), dim3(256), 0, st, a.blk_table, a.blk_info, n_blocks, 8u * a.nlead);
+            continue;
+        }
+        const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
+        a.work_counter = ctx->work_counters + slot;
+        a.block_pass = pass;
+        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(kernel, dim3(g), dim3(256), L.total, st, a);
+    }
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
 int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_dict, const uint8_t* d_in,
                     const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                     const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, size_t n_streams,
@@ -265,6 +354,11 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.cut_run = conf->extended ? 3u : 0u;  // (doubles per stream whenever a cut turns out to be superfluous)
     if (const char* e = getenv("TAMP_AMD_CUT_RUN")) { const int v = atoi(e); a.cut_run = (conf->extended && v >= 2 && v <= 64) ? (uint32_t)v : 0u; }
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
+    a.blk_table = nullptr, a.blk_info = nullptr, a.block_pass = 0, a.n_blocks = 0;
+    if (n_streams == 1 && !seg) {  // ONE long v1 stream: its blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>)
+        const int rc = launch_compress_blocks(ctx, a, conf, max_in_len, st);
+        if (rc != 1) return rc;
+    }
     const uint32_t W = 1u << conf->window;
     const bool packed = conf->window <= 14;  // u32 index entries; 2^15 windows fall back to u16 positions
     // run-list build: long runs of one byte leave the bigram index; default parse only
@@ -2077,8 +2171,30 @@ tamp_res segment_core(const TampAmdConf* conf, int emit_header, int append_marke
         stbuf[W + 6] = (unsigned char)(carry->ext_pos & 0xFF), stbuf[W + 7] = (unsigned char)(carry->ext_pos >> 8);
         for (int k = 0; k < 4; k++) stbuf[W + 16 + k] = (unsigned char)(carry->bits >> (8 * k));
     }
-    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_state, d_dict;
     const uint64_t zero = 0;
+    if (finish && !flush_token && !resume && emit_header && !append_marker && prefix.empty() && !conf->extended &&
+        !conf->lazy_matching && conf->literal == 8 && conf->window <= 14 && input_size >= ((size_t)256 << 10) &&
+        input_size <= 0xFFFFFF00ull) {
+        // A whole fresh v1 stream in one finishing call: the batch call takes it as ONE stream and spreads its blocks over
+        // all workgroups (launch_compress_blocks).  The object afterwards holds what the reference's would: every consumed
+        // byte was written (compressor.c:651-657), so the window is the stream's last W bytes at their ring positions.
+        const uint32_t ilen1 = (uint32_t)input_size;
+        const uint32_t ocap1 = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);
+        uint32_t olen1 = 0;
+        int8_t st1 = TAMP_ERROR;
+        rc = tamp_batch_compress(conf, conf->use_custom_dictionary ? window_state : nullptr, input, &zero, &ilen1, output, &zero,
+                                 &ocap1, &olen1, &st1, 1, ilen1, TAMP_AMD_MEM_HOST, device, nullptr);
+        if (rc != TAMP_OK) return (tamp_res)rc;
+        if (output_written_size) *output_written_size = olen1;
+        if (st1 == TAMP_OK) {
+            const size_t first = input_size > W ? input_size - W : 0;
+            for (size_t p2 = first; p2 < input_size; p2++) window_state[p2 & (W - 1)] = input[p2];
+            *window_pos = (uint16_t)(input_size & (W - 1));
+            if (carry) std::memset(carry, 0, sizeof *carry);
+        }
+        return st1;
+    }
+    DevBuf d_in, d_out, d_io, d_il, d_oo, d_oc, d_ol, d_st, d_state, d_dict;
     if ((uint64_t)prefix.size() + (uint64_t)input_size > 0xFFFFFFFFull) return TAMP_AMD_BAD_ARGUMENT;  // (32-bit stream lengths)
     const uint32_t ilen = (uint32_t)(prefix.size() + input_size);
     const uint32_t ocap = (uint32_t)(output_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : output_size);

@@ -80,6 +80,12 @@ struct CompressArgs {
     unsigned long long* prof;  // optional: per-phase cycle sums (debug builds with -DTAMP_PROF)
     uint32_t cut_run;          // epoch cut: a run of this many aligned dwords of one byte ends the block (0 = off)
     uint32_t dbg;              // debug builds only: bit mask of phases to skip (instruction-count experiments)
+    // BLOCK builds (round 5: ONE long v1 stream spread over all workgroups, see the template parameter BLOCKM): the "streams"
+    // the work counter hands out are the stream's blocks of `blk` positions
+    uint32_t* blk_table;            // n_blocks x 16 words, pass 1 writes: entry offset e -> exit offset | bits of the chain << 4
+    unsigned long long* blk_info;   // n_blocks, pass 2 writes and pass 3 reads: bit position of the block's first token << 4 | entry offset
+    uint32_t block_pass;            // 1 = tables, 3 = walk + emit
+    uint32_t n_blocks;
 };
 
 // LDS carve-up, shared by the host launcher and the kernel.
@@ -776,8 +782,21 @@ __device__ __forceinline__ T* as_global(T* p) {
     return (T*)(__attribute__((address_space(1))) T*)reinterpret_cast<uintptr_t>(p);
 }
 
-template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false>
+// BLOCKM (round 5): one LONG stream of the v1 format over all workgroups.  Without RLE / extended-match tokens every token
+// writes exactly the bytes it consumes (compressor.c:651-657), so the window at input position p is input[p - W, p) (the
+// dictionary where that reaches in front of the stream) HOWEVER the earlier bytes were parsed: find_best_match can be
+// evaluated for any block of positions by any workgroup.  What a block's parse depends on is only WHERE it starts -- the
+// previous block's last token reaches up to 14 bytes (minimum pattern + 13 - 1) into it.  Three launches:
+//   pass 1 (this kernel, block_pass = 1): per block, match phase + jump tables, then for each of the 15 possible entry
+//           offsets the chain's exit offset into the next block and the bits its tokens take (blk_table);
+//   pass 2 (tamp_block_scan_kernel): one serial walk over the blocks' tables: entry offset and bit position of every block;
+//   pass 3 (this kernel, block_pass = 3): match phase again, the walk from the block's true entry, the emitter's bits
+//           ORed into the output at the block's bit position (first and last dword atomically: neighbours share them).
+// The work counter hands out blocks instead of streams.  Reference shape: ONE stream of 100 MB (README.md:309-312,
+// tools/c-profiler/main.c:52-54), which one workgroup takes 6 s for.
+template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false, bool BLOCKM = false>
 __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) tamp_compress_kernel(CompressArgs a_k) {
+    static_assert(!BLOCKM || (LOOP && PACKED && !LAZY && !RUNS), "block mode: the lean persistent build");
     // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
@@ -821,6 +840,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
             a_l.out = as_global(a_l.out), a_l.out_off = as_global(a_l.out_off), a_l.out_cap = as_global(a_l.out_cap);
             a_l.out_len = as_global(a_l.out_len), a_l.status = as_global(a_l.status), a_l.dict = as_global(a_l.dict);
             a_l.state = as_global(a_l.state), a_l.work_counter = as_global(a_l.work_counter), a_l.prof = as_global(a_l.prof);
+            a_l.blk_table = as_global(a_l.blk_table), a_l.blk_info = as_global(a_l.blk_info);
         }
         const CompressArgs& a = LOOP ? a_l : a_k;
         const uint32_t a_wbits = a.wbits, a_blk = a.blk;
@@ -893,14 +913,26 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
         }
         // per-stream table entries are wave-uniform but arrive through vector loads (the compiler cannot prove the
         // tables invariant): pin them to scalar registers, or the two base pointers sit in VGPR pairs -- and spill
-        const uint8_t* const in = a.in + uni_u64(a.in_off[s]);
-        const uint32_t n = Walk::uni(a.in_len[s]);
-        uint8_t* const gout = a.out + uni_u64(a.out_off[s]);
-        const uint32_t cap = Walk::uni(a.out_cap[s]);
+        const uint32_t si = BLOCKM ? 0u : s;  // (block mode: `s` is the block, the tables have one row)
+        const uint8_t* const in = a.in + uni_u64(a.in_off[si]);
+        const uint32_t n = Walk::uni(a.in_len[si]);
+        uint8_t* const gout = a.out + uni_u64(a.out_off[si]);
+        const uint32_t cap = Walk::uni(a.out_cap[si]);
+        const uint32_t bpos = BLOCKM ? s * a_blk : 0u;  // block mode: input position of this block
+        unsigned long long binfo = 0;                   // ... and (pass 3) bit position << 4 | entry offset
+        if constexpr (BLOCKM) {
+            if (a.block_pass == 3) binfo = uni_u64(a.blk_info[s]);
+        }
 
         uint8_t* const st_io = a.state ? a.state + (size_t)s * (W + kSegStateExtra) : nullptr;
         const bool partial = (a.seg_flags & kSegPartial) != 0;
         uint32_t wp0 = 0;
+        if constexpr (BLOCKM) {
+            // window <- the W bytes in front of the block, oldest first: input, or -- in front of the stream -- the dictionary
+            // byte that still sits at that ring index (window_pos of a fresh stream = bytes written mod W)
+            wp0 = bpos & mask;
+            for (uint32_t k = tid; k < W; k += nt) ebuf[k] = (bpos + k >= W) ? in[bpos + k - W] : a.dict[(bpos + k) & mask];
+        } else
         if (st_io && (a.seg_flags & kSegResume)) {
             // window <- saved state (ring order) rotated so that the oldest byte comes first
             wp0 = (uint32_t)st_io[W] | ((uint32_t)st_io[W + 1] << 8);
@@ -922,7 +954,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
         }
         // bit buffer: leading bytes (header, compressor.c:236-241; FLUSH + pad when appending, :227-235) or the carried
         // bits, rest zero
-        const uint32_t word0 = a.nlead ? (uint32_t)a.lead << 16 : (c_nbits ? c_bits & (0xFFFFFFFFu << (32 - c_nbits)) : 0u);
+        const uint32_t word0 = (BLOCKM && s != 0) ? 0u : (a.nlead ? (uint32_t)a.lead << 16 : (c_nbits ? c_bits & (0xFFFFFFFFu << (32 - c_nbits)) : 0u));
         for (uint32_t k = tid; k < L.obuf_words; k += nt) obuf[k] = k == 0 ? __builtin_bswap32(word0) : 0;
 
         Walk wk;
@@ -938,12 +970,12 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #endif
         wk.lazy = lazy, wk.lazy_valid = false, wk.lazy_idx = 0, wk.lazy_len = 0, wk.blen2 = blen2, wk.bidx2 = bidx2;
         if (tid_k == 0) ctl[cCutThr] = a.cut_run;  // (read after the load phase's barrier)
-        uint32_t w_p0 = 0;  // wave 0: input position of ebuf[W]
+        uint32_t w_p0 = bpos;  // wave 0: input position of ebuf[W]
 
         // workgroup-uniform output state
-        uint32_t carry = a.nlead ? 8u * a.nlead : c_nbits;  // bits already sitting in obuf
+        uint32_t carry = BLOCKM ? ((uint32_t)(binfo >> 4) & 31u) : (a.nlead ? 8u * a.nlead : c_nbits);  // bits already sitting in obuf
         uint32_t gpos = 0;                         // bytes already flushed to HBM
-        uint32_t e_p0 = 0, e_pending = c_rle + c_ext, e_wp = wp0;  // epoch parameters
+        uint32_t e_p0 = bpos, e_pending = c_rle + c_ext, e_wp = wp0;  // epoch parameters
         bool need_match = true;
         // Positions matched per epoch.  A token that breaks the speculation throws the rest of the block away, so
         // after such a break the next block is small (data with long runs / window-end truncations tends to break
@@ -1661,14 +1693,24 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // finished << 18.  A round is five VALU operations: the count field of the own state is added onto
                     // the state fetched from the target (which brings target, count and the finished bit along; counts
                     // stay below 256, nothing carries), finished lanes keep theirs.
-                    constexpr uint32_t kFin = 1u << 18, kCnt = 0xFFu << 10;
+                    constexpr uint32_t kFin = 1u << 18, kCnt = (0xFFu << 10) | (BLOCKM ? 0xFFF80000u : 0u);
                     uint32_t st = slowp ? (((uint32_t)lane << 2) | kFin) : ((((uint32_t)lane + stepv) << 2) | (1u << 10));
+                    if constexpr (BLOCKM) {
+                        // block mode: the bits of the chain's tokens ride along in bits 19.. (a 64-position block's tokens
+                        // take 64 x 9 + 24 bits at most: literal 1 + 8, match prefix code + window bits per two positions or more)
+                        const uint32_t lenv = sv & 0x1Fu;
+                        const uint32_t tb = lenv >= minp ? tok_nbits(lenv - minp) + wbits : lbits + 1u;
+                        if (!slowp) st |= tb << 19;
+                    }
                     if ((st & 0x3FFu) >= 256u) st |= kFin;
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
                         const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(st & 0x3FFu), (int)st);
                         const uint32_t nw = o2 + (st & kCnt);
                         st = (st & kFin) ? st : nw;
+                    }
+                    if constexpr (BLOCKM) {
+                        if (a.block_pass == 1 && b + lane < nv) toklist[b + lane] = (uint16_t)(st >> 19);  // (pass 1 lists no tokens: the space is free)
                     }
                     st = ((st & 0x3FFu) >> 2) | (((st >> 10) & 0xFFu) << 8);  // target | count << 8 for the stores below
                     if (b + lane < nv) {
@@ -1682,6 +1724,25 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 }
                 __syncthreads();
                 TAMP_PROF_MARK(2);
+            }
+            if constexpr (BLOCKM) {
+                if (a.block_pass == 1) {
+                    // per entry offset (the previous block's last token reaches up to 14 bytes into this one): where the chain
+                    // of tokens leaves the block and how many bits it takes -- sixteen dependent reads per lane, 15 lanes
+                    if (tid < 16) {
+                        uint32_t pos = tid, bits = 0;
+                        bool ok = tid < 15;
+                        while (ok && pos < nvalid) {
+                            const uint32_t jc = jc32[pos], j = jc & 0xFFFFu;
+                            if (j == pos) { ok = false; break; }  // (a position the state machine would take: none in the v1 format)
+                            bits += toklist[pos];
+                            pos = j;
+                        }
+                        a.blk_table[(size_t)s * 16 + tid] = ok ? ((pos - nvalid) | (bits << 4)) : 0xFFFFFFFFu;
+                    }
+                    break;
+                }
+                wk.rd = wk.wr = (uint32_t)binfo & 15u;  // pass 3: the walk starts where the previous block's last token ended
             }
 
             // ---------------- walk: wave 0 ----------------
@@ -2039,6 +2100,40 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 st_io[W + 5] = (uint8_t)nb;
                 st_io[W + 16] = 0, st_io[W + 17] = 0, st_io[W + 18] = 0;
                 st_io[W + 19] = nb ? reinterpret_cast<const uint8_t*>(obuf)[tot >> 3] : 0;
+            }
+            if constexpr (BLOCKM) {
+                // Block mode: the bit buffer's word 0 is word (bit position >> 5) of the stream's output; this block owns the
+                // bytes [c0, c1) of it -- the first and the last one possibly together with a neighbour, whose bits are zero
+                // here.  Aligned dwords of the destination: the first and the last are ORed in atomically (the output was
+                // zeroed before the launch), the ones in between are stored.  Nothing is written at or behind `cap`.
+                const uint8_t* ob = reinterpret_cast<const uint8_t*>(obuf);
+                const unsigned long long base = ((binfo >> 4) >> 5) << 2;  // output byte index of ob[0]
+                const uint32_t c0 = s == 0 ? 0u : carry >> 3, c1 = (tot + 7) >> 3;
+                const uint32_t c1c = base + c1 <= cap ? c1 : (base >= cap ? 0u : (uint32_t)(cap - base));
+                if (c1c > c0) {
+                    uint8_t* const P = gout + base;
+                    const uintptr_t A0 = reinterpret_cast<uintptr_t>(P + c0) & ~(uintptr_t)3, A1 = reinterpret_cast<uintptr_t>(P + c1c - 1) & ~(uintptr_t)3;
+                    const uint32_t ndw = (uint32_t)((A1 - A0) >> 2) + 1;
+                    for (uint32_t j = tid; j < ndw; j += nt) {
+                        uint32_t* const dst = reinterpret_cast<uint32_t*>(A0 + 4 * (uintptr_t)j);
+                        const int32_t i0 = (int32_t)(reinterpret_cast<intptr_t>(dst) - reinterpret_cast<intptr_t>(P));  // ob index of its first byte
+                        uint32_t v = 0;
+                        if (i0 >= (int32_t)c0 && i0 + 4 <= (int32_t)c1c) {
+                            v = lds_u32_unaligned(ob, (uint32_t)i0);
+                        } else {
+                            for (int32_t x = 0; x < 4; x++)
+                                if (i0 + x >= (int32_t)c0 && i0 + x < (int32_t)c1c) v |= (uint32_t)ob[i0 + x] << (8 * x);
+                        }
+                        if (j == 0 || j == ndw - 1) atomicOr(dst, v);
+                        else *dst = v;
+                    }
+                }
+                if (act == kActDone && tid == 0) {
+                    const unsigned long long total_bytes = base + c1;
+                    a.out_len[0] = total_bytes < cap ? (uint32_t)total_bytes : cap;
+                    a.status[0] = total_bytes > cap ? kOutputFull : kOk;
+                }
+                break;  // (one epoch per block)
             }
             {   // HBM stores are whole aligned dwords whatever the slab's byte alignment: a few head bytes, then
                 // dwords funnel-shifted out of the bit buffer, then the tail bytes
