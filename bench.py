@@ -342,6 +342,10 @@ def main():
         except Exception as e:
             also["real_text"] = {"error": repr(e)[:200]}
         try:
+            also["one_long_stream"] = also_one_long_stream(torch, np)
+        except Exception as e:  # noqa: BLE001
+            also["one_long_stream"] = {"error": repr(e)[:200]}
+        try:
             also["strong_scaling_standin"] = also_strong_scaling(args, torch, np)
         except Exception as e:  # noqa: BLE001
             also["strong_scaling_standin"] = {"error": repr(e)[:200]}
@@ -378,6 +382,35 @@ def also_configs1(args, torch, np, conf_kw, steps=10, warmup=3):
     return {"workload": "65536 x 4096 B synthetic text, window=10 literal=8 extended=%d" % int(conf_kw["extended"]),
             "kernel_ms": round(k_ms, 4), "input_GBps": round(sh.in_bytes / (k_ms * 1e-3) / 1e9, 2),
             "all_streams_ok": bool((res.status == 0).all().item())}
+
+
+def also_one_long_stream(torch, np, n=100_000_000):
+    """ONE stream of enwik8's length (the reference's own benchmark shape, /root/reference/README.md:309-312) in the v1
+    format: its 1,024-position blocks spread over all workgroups (tamp_compress_kernel<.., BLOCKM>).  The
+    frozen prose corpus tiled to 100,000,000 bytes, resident in HBM; kernel time of the whole call (zero fill, tables, scan,
+    emit); a 4 MiB stream of the same text checked against the reference C (the 100 MB one: tests/test_gpu_round5.py)."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    dev = torch.device("cuda", 0)
+    blob = wl.real_text("prose")
+    flat = np.frombuffer((blob * (n // len(blob) + 1))[:n], dtype=np.uint8).copy()
+    d = torch.from_numpy(flat).to(dev)
+    off = torch.zeros(1, dtype=torch.int64, device=dev)
+    ln = torch.tensor([n], dtype=torch.int32, device=dev)
+    ms, r = [], None
+    for _ in range(4):
+        r = tamp_amd.compress_batch(d, off, ln, window=10, literal=8, extended=False, max_in_len=n, timing=True)
+        ms.append(float(r.kernel_ms))
+    kind, impl = _checker()
+    k = 4 << 20
+    want = impl.compress_batch(flat[:k], np.zeros(1, np.uint64), np.array([k], np.uint32), window=10, literal=8, extended=False).stream(0)
+    got = tamp_amd.compress_batch(d[:k], off, torch.tensor([k], dtype=torch.int32, device=dev), window=10, literal=8,
+                                  extended=False, max_in_len=k).stream(0)
+    return {"bytes": n, "format": "v1 (extended=0), window=10 literal=8", "kernel_ms": round(min(ms[1:]), 3),
+            "input_GBps": round(n / (min(ms[1:]) * 1e-3) / 1e9, 2), "status": int(r.status[0]),
+            "ratio": round(int(r.out_len[0]) / n, 4), "parity_4MiB_stream": ("bit-exact" if got == want else "MISMATCH") + f" vs {kind}",
+            "note": "extended-format streams keep one workgroup per stream: their lags make the window depend on the parse"}
 
 
 def also_strong_scaling(args, torch, np, reps=5):

@@ -232,35 +232,58 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     return blk;
 }
 
-// Block mode, pass 2: entry offset and bit position of every block, one serial walk over the tables of pass 1 (a dependent
-// LDS read per block: ~4 ms for the 97,657 blocks of a 100 MB stream).  One workgroup; 512 blocks' tables per round.
-__global__ void __launch_bounds__(256) tamp_block_scan_kernel(const uint32_t* table, unsigned long long* info, uint32_t n_blocks,
-                                                              uint32_t lead_bits) {
-    constexpr uint32_t kRound = 512;
-    __shared__ uint32_t t[kRound * 16];
-    __shared__ unsigned long long res[kRound];
-    __shared__ unsigned long long carry_bp;
-    __shared__ uint32_t carry_entry;
-    if (threadIdx.x == 0) carry_bp = lead_bits, carry_entry = 0;
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += kRound) {
-        const uint32_t cnt = n_blocks - b0 < kRound ? n_blocks - b0 : kRound;
-        for (uint32_t i = threadIdx.x; i < cnt * 16; i += blockDim.x) t[i] = table[(size_t)b0 * 16 + i];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long bp = carry_bp;
-            uint32_t entry = carry_entry;
+// Block mode, pass 2: entry offset and bit position of every block from the tables of pass 1 -- a chain of one dependent
+// table look-up per block.  Two levels keep it short: chunks of 512 blocks.  tamp_block_scan_chunks: per chunk, for each of
+// the 15 entry offsets (a lane each) where the chain leaves the chunk and the bits it takes.  tamp_block_scan_kernel: per
+// chunk, the chain over the CHUNK tables in front of it (a few hundred steps at most for 4 GiB), then the chunk's own 512
+// blocks from its true entry.  (One workgroup walking all 97,657 blocks of a 100 MB stream took 4 ms of the call's 11.)
+constexpr uint32_t kScanChunk = 512;
+__global__ void __launch_bounds__(256) tamp_block_scan_chunks(const uint32_t* table, uint32_t* chunk_table /* n_chunks x 16 x 2 */,
+                                                              uint32_t n_blocks) {
+    __shared__ uint32_t t[kScanChunk * 16];
+    const uint32_t b0 = blockIdx.x * kScanChunk;
+    const uint32_t cnt = n_blocks - b0 < kScanChunk ? n_blocks - b0 : kScanChunk;
+    for (uint32_t i = threadIdx.x; i < cnt * 16; i += blockDim.x) t[i] = table[(size_t)b0 * 16 + i];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        uint32_t entry = threadIdx.x;
+        unsigned long long bits = 0;
+        if (threadIdx.x < 15)
             for (uint32_t i = 0; i < cnt; i++) {
-                res[i] = (bp << 4) | entry;
                 const uint32_t v = t[i * 16 + entry];
                 entry = v & 15u;
-                bp += v >> 4;
+                bits += v >> 4;
             }
-            carry_bp = bp, carry_entry = entry;
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) info[b0 + i] = res[i];
-        __syncthreads();
+        // (exit offset | bits << 4 does not fit 32 bits for 512 blocks of 9 Kbit: two words)
+        chunk_table[((size_t)blockIdx.x * 16 + threadIdx.x) * 2] = entry;
+        chunk_table[((size_t)blockIdx.x * 16 + threadIdx.x) * 2 + 1] = (uint32_t)bits;
     }
+}
+__global__ void __launch_bounds__(256) tamp_block_scan_kernel(const uint32_t* table, const uint32_t* chunk_table, unsigned long long* info,
+                                                              uint32_t n_blocks, uint32_t lead_bits) {
+    __shared__ uint32_t t[kScanChunk * 16];
+    __shared__ unsigned long long res[kScanChunk];
+    const uint32_t b0 = blockIdx.x * kScanChunk;
+    const uint32_t cnt = n_blocks - b0 < kScanChunk ? n_blocks - b0 : kScanChunk;
+    for (uint32_t i = threadIdx.x; i < cnt * 16; i += blockDim.x) t[i] = table[(size_t)b0 * 16 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bp = lead_bits;
+        uint32_t entry = 0;
+        for (uint32_t c = 0; c < blockIdx.x; c++) {  // the chunks in front of this one
+            const uint32_t* e = chunk_table + ((size_t)c * 16 + entry) * 2;
+            bp += e[1];
+            entry = e[0];
+        }
+        for (uint32_t i = 0; i < cnt; i++) {
+            res[i] = (bp << 4) | entry;
+            const uint32_t v = t[i * 16 + entry];
+            entry = v & 15u;
+            bp += v >> 4;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) info[b0 + i] = res[i];
 }
 
 // Block mode (tamp_compress_kernel<.., BLOCKM>): ONE long stream of the v1 format, literal 8, default parse, fresh window.
@@ -286,10 +309,12 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     const CompressLds L(W, a.blk, true, false, false);
     if (L.total > ctx->lds_per_block) return 1;
     const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
-    const size_t table_bytes = (size_t)n_blocks * 16 * 4, info_bytes = (size_t)n_blocks * 8;
-    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + 256));
+    const uint32_t n_chunks = (n_blocks + kScanChunk - 1) / kScanChunk;
+    const size_t table_bytes = ((size_t)n_blocks * 16 * 4 + 255) & ~(size_t)255, info_bytes = ((size_t)n_blocks * 8 + 255) & ~(size_t)255;
+    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256));
     a.blk_table = static_cast<uint32_t*>(ctx->blk_scratch.p);
-    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + ((table_bytes + 255) & ~(size_t)255));
+    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes);
+    uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes + info_bytes);
     a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
     auto kernel = tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
@@ -303,7 +328,8 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     HIP_OK(hipMemsetAsync(a.out + row.out_off, 0, (size_t)std::min<uint64_t>(bound, row.out_cap), st));
     for (uint32_t pass = 1; pass <= 3; pass++) {
         if (pass == 2) {
-            hipLaunchKernelGGL(tamp_block_scan_kernel, dim3(1), dim3(256), 0, st, a.blk_table, a.blk_info, n_blocks, 8u * a.nlead);
+            hipLaunchKernelGGL(tamp_block_scan_chunks, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, n_blocks);
+            hipLaunchKernelGGL(tamp_block_scan_kernel, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, a.blk_info, n_blocks, 8u * a.nlead);
             continue;
         }
         const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;

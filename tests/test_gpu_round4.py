@@ -168,7 +168,10 @@ def test_bench_strong_scaling_standin_as_invoked():
     assert "STAND-IN" in whole["config"]["workload"]
     part = _bench(["--corpus-standin", "--shard-fraction", "8", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], {})
     assert 3040 <= part["config"]["streams_total"] <= 3064 and part["config"]["all_streams_ok"]
-    assert part["ms_per_step"] < whole["ms_per_step"] / 4  # (an eighth of the work: well under a quarter of the time)
+    # an eighth of the work -- but NOT an eighth of the time: a 3,052-stream batch is 1.7 rounds of the 1,792-workgroup grid
+    # and no faster than its slowest stream (one workgroup per stream: 1.4 ms for the heaviest chunk of Python source,
+    # tools/solo_latency.py).  Measured 3.1-3.3 x; the bench line carries the figure (also.strong_scaling_standin).
+    assert part["ms_per_step"] < whole["ms_per_step"] / 2.5
 
 
 def test_build_dictionary_cli_end_to_end(tmp_path, ta):
