@@ -364,6 +364,70 @@ struct Walk {
     // index" among the candidates >= the first match -- which one search with the whole look-ahead finds directly.
     // Candidate rounds [4 * g0, 4 * g1) of the search (a round = one candidate per lane, 64 apart): the best key of this
     // wavefront's lanes.  key = length << 16 | ~candidate: longest, ties -> lowest candidate, whatever the order of evaluation.
+#ifndef TAMP_OLD_EXT_SEARCH
+    // Round 5: the filter looks at the candidate's FIRST four bytes as well as at the four around the current end (a 4-byte
+    // filter alone passes two to five false candidates per search in 1 KiB of text, and each cost every lane of its
+    // wavefront a serial byte-by-byte verification), and whatever passes is compared by the whole wavefront at once -- four
+    // bytes a lane against pattern + look-ahead, ring order on the window's side, one ballot -- instead of by its own lane in
+    // a loop: 1.2 k -> ~0.5 k VALU wave-instructions per search over the four wavefronts (profiles/r5_phase_valu.csv: the
+    // walk was 14 / 27 / 18 % of all instructions on prose / markup / Python sources, nearly all of it searches).
+    __device__ __forceinline__ uint32_t ext_search_rounds(uint32_t avail, uint32_t g0, uint32_t g1) const {
+        const uint32_t pos = ext_pos, cnt = ext_count;
+        const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
+        // (the consumed bytes ARE the pattern: input [rd-cnt, rd) == window[pos, pos+cnt))
+        const uint32_t tail4 = uni(lds_u32_unaligned(ebuf, W + rd - 3));   // bytes cnt-3 .. cnt: the last three consumed + the next input byte
+        const uint32_t head4 = uni(lds_u32_unaligned(ebuf, W + rd - cnt));
+        const uint32_t nextb = tail4 >> 24;
+        const uint32_t wpv = wp();
+        const uint32_t inp = lds_u32_unaligned(ebuf, W + rd - cnt + 4u * (uint32_t)lane);  // pattern + look-ahead, four bytes a lane
+        uint32_t key = 0;  // wave-uniform
+        for (uint32_t cb0 = pos; cb0 + cnt + 1 <= W; cb0 += 16 * kWave) {
+            for (uint32_t g = g0; g < g1; g++) {
+                if (4 * g * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
+                if (cb0 + 4 * g * kWave + cnt + 1 > W) break;  // (no candidate of this and the later rounds is in range)
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t cb = cb0 + (4 * g + j) * kWave;  // lane 0's candidate of this step
+                    const uint32_t c = cb + (uint32_t)lane;
+                    const bool valid = c + cnt + 1 <= W;
+                    const uint32_t r0 = ((valid ? c : pos) - wpv) & mask;  // oldest-first offset of the candidate's first byte
+                    const uint32_t r = (r0 + cnt - 3) & mask;
+                    bool hit = lds_u32_unaligned(ebuf, wr + r) == tail4;
+                    if (r > W - 4) hit = ebuf[wr + ((r + 3) & mask)] == nextb;  // the four bytes straddle the write cursor
+                    bool hit0 = lds_u32_unaligned(ebuf, wr + r0) == head4;
+                    if (r0 > W - 4) hit0 = true;                                // (likewise: left to the compare)
+                    uint64_t bal = __ballot(valid && hit && hit0);
+                    while (bal) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(bal);
+                        bal &= bal - 1;
+                        const uint32_t ci = cb + f;                      // window index of the candidate (uniform)
+                        const uint32_t rc = (ci - wpv) & mask;
+                        uint32_t o = rc + 4u * (uint32_t)lane;
+                        uint32_t cand;
+                        if (o + 3 >= W && o < W) {  // (at most one lane: its four bytes straddle the newest byte)
+                            cand = 0;
+                            for (uint32_t b = 0; b < 4; b++) cand |= (uint32_t)ebuf[wr + ((o + b) & mask)] << (8 * b);
+                        } else {
+                            if (o >= W) o -= W;
+                            cand = lds_u32_unaligned(ebuf, wr + o);
+                        }
+                        const uint32_t x = cand ^ inp;
+                        const uint64_t diff = __ballot(x != 0);
+                        uint32_t lcp = 256;
+                        if (diff) {
+                            const uint32_t fl = (uint32_t)__builtin_ctzll(diff);
+                            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl);
+                            lcp = 4u * fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+                        }
+                        const uint32_t len = min(lcp, min(maxp, W - ci));
+                        if (len >= cnt + 1) key = max(key, (len << 16) | (0xFFFFu - ci));
+                    }
+                }
+            }
+        }
+        return uni(key);
+    }
+#else
     __device__ __forceinline__ uint32_t ext_search_rounds(uint32_t avail, uint32_t g0, uint32_t g1) const {
         const uint32_t pos = ext_pos, cnt = ext_count;
         const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
@@ -404,6 +468,8 @@ struct Walk {
         }
         return wave_max_u32(key);
     }
+
+#endif
 
     enum : uint32_t { kCoopCmd = 17, kCoopA = 1, kCoopB = 2, kCoopC = 3, kCoopD = 4, kCoopE = 18, kCoopF = 19, kCoopKey = 8 };  // ctl words (free during the walk)
     enum : uint32_t { kCmdEnd = 0, kCmdExtSearch = 1, kCmdBest = 2 };
@@ -1299,8 +1365,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #ifdef TAMP_PROF
                                     // (0x8000: instruction-count experiment -- the loop without its 16-byte compares, i.e.
                                     // what any scheme that takes the deep compares elsewhere leaves behind; results are wrong)
-                                    if ((x >> kRem) == 0 && !(a.dbg & 0x8000u)) len = prefix_len16(ebuf, c, P);
-                                    else if ((x >> kRem) == 0) len = 4u;
+                                    if ((x >> kRem) == 0 && !(a.dbg & 0x8000u)) {
+                                        len = prefix_len16(ebuf, c, P);
+                                        if (a.dbg & 0x1000000u) {  // (round 5: the compare once more -- same result -- for its exact count)
+                                            asm volatile("" ::: "memory");
+                                            len = max(len, prefix_len16(ebuf, c, P));
+                                        }
+                                    } else if ((x >> kRem) == 0) len = 4u;
 #else
                                     if ((x >> kRem) == 0) len = prefix_len16(ebuf, c, P);  // next two bytes agree too
 #endif
@@ -1458,7 +1529,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // revisits its own queries).  Interior positions within 15 bytes of the newest window byte run into
                     // the oldest ones like their indexed neighbours (prefix_len_wrapped16).
 #ifdef TAMP_PROF
-                    if (nruns && !(a.dbg & 0x4000u)) {  // (0x4000: instruction-count experiments without the second pass)
+                    if (nruns && !(a.dbg & 0x4000u))  // (0x4000: instruction-count experiments without the second pass)
+                    TAMP_REPEAT(0x2000000u) {         // (0x2000000: twice -- the second time it finds its own results -- for its count)
 #else
                     if (nruns) {
 #endif
@@ -1592,6 +1664,12 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // input and matches with rivals stay with the state machine.
                     if (ext && (kSlowCap * 8 + a_blk) <= kHashBuckets * 2) {
                         const uint32_t max_ext = minp + 11 + kExtExtraMax;
+#ifdef TAMP_PROF
+                        // (0x4000000: a dry run in front -- everything but the stores -- for the pass's instruction count)
+                        for (uint32_t dry = (a.dbg & 0x4000000u) ? 1u : 0u; dry != 0xFFFFFFFFu; dry--)
+#else
+                        constexpr uint32_t dry = 0;
+#endif
                         for (uint32_t q = e_pending + tid; q < nvalid; q += nt) {
                             const uint32_t sv = blen[q];
                             if (!(sv & 0x80u)) continue;
@@ -1610,11 +1688,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                 const uint32_t r = 2u + (x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4u + (x1 ? (uint32_t)__builtin_ctz(x1) >> 3 : 4u));
                                 if (r > kRleWindowMax || r >= leftq || wpq + r > W) continue;
                                 if (r <= 6 && len > r) {  // the pattern wins: an ordinary match step (or an extended match: slow)
-                                    if (len <= minp + 11) blen[q] = (uint8_t)len;
+                                    if (len <= minp + 11 && !dry) blen[q] = (uint8_t)len;
                                     continue;
                                 }
-                                blen[q] = (uint8_t)(0x20u | 1u);
-                                xcnt[q] = (uint8_t)r;
+                                if (!dry) blen[q] = (uint8_t)(0x20u | 1u), xcnt[q] = (uint8_t)r;
                                 continue;
                             }
                             if (!(sv & 0x40u)) continue;
@@ -1635,8 +1712,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             // (kSegPartial: the reference takes this match a 16-byte ring at a time; the poll that emits
                             // the token must still have had a full ring)
                             if (partial && leftq < cnt + kRing) continue;
-                            blen[q] = (uint8_t)(0x20u | len);
-                            xcnt[q] = (uint8_t)cnt;
+                            if (!dry) blen[q] = (uint8_t)(0x20u | len), xcnt[q] = (uint8_t)cnt;
                         }
                     }
                     __syncthreads();
@@ -1751,6 +1827,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 // it, and it shares its SIMD with five wavefronts of other workgroups: let the issue arbiter prefer it
                 // (kPrioWalk; see kPrioScan for the scheme).
                 __builtin_amdgcn_s_setprio(kPrioWalk);
+#ifdef TAMP_PROF
+                // (0x8000000: the walk's main loop TWICE from the same state, for its instruction count -- what it writes
+                // to LDS is the same both times, positions matched on demand are marked "deferred" again in between;
+                // with 0x10000000 the second run skips the token listing: the difference is the listing's count)
+                const Walk wk_save = wk;
+                uint32_t walk_reps = (a.dbg & 0x8000000u) ? 2u : 1u, ndef = 0;
+                bool walk_second = false;
+            walk_again:
+#endif
                 wk.nvalid = nvalid;
                 wk.ntok = 0, wk.ns = 0;
                 uint32_t act = 0, excess_tok = 0xFFFFFFFFu;
@@ -1766,6 +1851,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #endif
                     __builtin_amdgcn_wave_barrier();
 #ifdef TAMP_PROF
+                    if ((a.dbg & 0x10000000u) && walk_second) { nqueued = 0; return; }
                     // (0x200000: the listing without its chain of dependent reads -- valid positions, wrong tokens: the
                     // time the chain costs)
                     if ((a.dbg & 0x200000u) && (uint32_t)lane < nqueued) {
@@ -1857,8 +1943,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             const uint32_t ec0 = wk.ext_count;
 #endif
                             if constexpr (!LAZY) {
-                                if (ext && wk.wr == wk.rd && wk.rd < nvalid && (Walk::uni(blen[wk.rd]) & 0x1Fu) == kDeferred)
+                                if (ext && wk.wr == wk.rd && wk.rd < nvalid && (Walk::uni(blen[wk.rd]) & 0x1Fu) == kDeferred) {
+#ifdef TAMP_PROF
+                                    if constexpr (RUNS) {
+                                        if (lane == 0 && ndef < kRunCap) runs[ndef] = wk.rd;  // (the run list is dead during the walk)
+                                        ndef++;
+                                    }
+#endif
                                     wk.best_on_demand(leftp < kRing ? leftp : kRing);  // (a position the match phase left out)
+                                }
                             }
                             r = wk.template step<RUNS>(leftp < kRing ? leftp : kRing, leftp);
 #ifdef TAMP_PROF
@@ -1908,6 +2001,18 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 }
                 list_queued();
 #ifdef TAMP_PROF
+                if (--walk_reps) {
+                    if constexpr (RUNS) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0)
+                            for (uint32_t k = 0; k < ndef && k < kRunCap; k++) blen[runs[k]] = (uint8_t)(0x80u | kDeferred);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    ndef = 0;
+                    wk = wk_save;
+                    walk_second = true;
+                    goto walk_again;
+                }
                 if (a.dbg & 0x2000u) wk.dbg_lag_rle += (uint32_t)dbg_hop, wk.dbg_lag_ext += (uint32_t)dbg_list, wk.dbg_lag_rle_short += (uint32_t)dbg_calls;
 #endif
                 if (act == kActRebase) {
