@@ -311,10 +311,17 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
     const uint32_t n_chunks = (n_blocks + kScanChunk - 1) / kScanChunk;
     const size_t table_bytes = ((size_t)n_blocks * 16 * 4 + 255) & ~(size_t)255, info_bytes = ((size_t)n_blocks * 8 + 255) & ~(size_t)255;
-    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256));
+    // (the match results of pass 1, 3 bytes per input byte, when that stays under 1.5 GiB: pass 3 then does not match again)
+    const size_t len_bytes = ((size_t)n + 1024 + 255) & ~(size_t)255;
+    const bool keep_tables = (size_t)n * 3 <= ((size_t)3 << 29) && !getenv("TAMP_AMD_BLOCK_REMATCH");
+    const size_t tables_bytes = keep_tables ? 3 * len_bytes : 0;
+    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256 + tables_bytes));
     a.blk_table = static_cast<uint32_t*>(ctx->blk_scratch.p);
     a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes);
     uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes + info_bytes);
+    uint8_t* const tables = static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes + info_bytes + (((size_t)n_chunks * 16 * 8 + 255) & ~(size_t)255);
+    a.blk_len = keep_tables ? tables : nullptr;
+    a.blk_idx = keep_tables ? reinterpret_cast<uint16_t*>(tables + len_bytes) : nullptr;
     a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
     auto kernel = tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
@@ -380,7 +387,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     a.cut_run = conf->extended ? 3u : 0u;  // (doubles per stream whenever a cut turns out to be superfluous)
     if (const char* e = getenv("TAMP_AMD_CUT_RUN")) { const int v = atoi(e); a.cut_run = (conf->extended && v >= 2 && v <= 64) ? (uint32_t)v : 0u; }
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
-    a.blk_table = nullptr, a.blk_info = nullptr, a.block_pass = 0, a.n_blocks = 0;
+    a.blk_table = nullptr, a.blk_info = nullptr, a.block_pass = 0, a.n_blocks = 0, a.blk_len = nullptr, a.blk_idx = nullptr;
     if (n_streams == 1 && !seg) {  // ONE long v1 stream: its blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>)
         const int rc = launch_compress_blocks(ctx, a, conf, max_in_len, st);
         if (rc != 1) return rc;

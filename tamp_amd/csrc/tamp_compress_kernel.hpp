@@ -86,6 +86,8 @@ struct CompressArgs {
     unsigned long long* blk_info;   // n_blocks, pass 2 writes and pass 3 reads: bit position of the block's first token << 4 | entry offset
     uint32_t block_pass;            // 1 = tables, 3 = walk + emit
     uint32_t n_blocks;
+    uint8_t* blk_len;               // optional, n bytes: pass 1 leaves every position's match length here ...
+    uint16_t* blk_idx;              // ... and its window index here, and pass 3 reads them instead of matching again
 };
 
 // LDS carve-up, shared by the host launcher and the kernel.
@@ -907,6 +909,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
             a_l.out_len = as_global(a_l.out_len), a_l.status = as_global(a_l.status), a_l.dict = as_global(a_l.dict);
             a_l.state = as_global(a_l.state), a_l.work_counter = as_global(a_l.work_counter), a_l.prof = as_global(a_l.prof);
             a_l.blk_table = as_global(a_l.blk_table), a_l.blk_info = as_global(a_l.blk_info);
+            a_l.blk_len = as_global(a_l.blk_len), a_l.blk_idx = as_global(a_l.blk_idx);
         }
         const CompressArgs& a = LOOP ? a_l : a_k;
         const uint32_t a_wbits = a.wbits, a_blk = a.blk;
@@ -1101,6 +1104,22 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 pt[12] += 1, pt[13] += nvalid;  // epochs, positions matched
 #endif
 
+                bool have_tables = false;
+                if constexpr (BLOCKM) {
+                    have_tables = a.block_pass == 3 && a.blk_len != nullptr;
+                    if (have_tables) {  // pass 3: what pass 1 matched for this block comes back from HBM
+                        const uint8_t* const gl = a.blk_len + bpos;
+                        const uint16_t* const gi = a.blk_idx + bpos;
+                        for (uint32_t k = tid * 4; k < nvalid; k += nt * 4) {
+                            *reinterpret_cast<uint32_t*>(blen + k) = *reinterpret_cast<const uint32_t*>(gl + k);
+                            *reinterpret_cast<uint2*>(bidx + k) = *reinterpret_cast<const uint2*>(gi + k);
+                        }
+                        __syncthreads();
+                        for (uint32_t k = nvalid + tid; k < nvalid + 128 && k < a_blk + 128; k += nt) blen[k] = 0x80;  // sentinels
+                        __syncthreads();
+                    }
+                }
+                if (!have_tables) {
                 // ---------------- index: counting sort of buffer positions by bigram ----------------
 #ifdef TAMP_PROF
                 uint32_t index_reps = (a.dbg & 0x20000u) ? 2u : 1u;
@@ -1717,6 +1736,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     }
                     __syncthreads();
                 }
+                }  // (!have_tables)
                 for (uint32_t k = 4 + tid; k < 4 + a_blk / 2 && k < L.obuf_words; k += nt) obuf[k] = 0;  // scan starts out
                 // Jump tables for the walk (the index is dead now, its space is reused).  Within each 64-position
                 // block, lane = position: six rounds of pointer doubling over ds_bpermute give, for every position, where
@@ -1815,6 +1835,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             pos = j;
                         }
                         a.blk_table[(size_t)s * 16 + tid] = ok ? ((pos - nvalid) | (bits << 4)) : 0xFFFFFFFFu;
+                    }
+                    if (a.blk_len) {  // the match results, for pass 3
+                        uint8_t* const gl = a.blk_len + bpos;
+                        uint16_t* const gi = a.blk_idx + bpos;
+                        for (uint32_t k = tid * 4; k < nvalid; k += nt * 4) {
+                            *reinterpret_cast<uint32_t*>(gl + k) = *reinterpret_cast<const uint32_t*>(blen + k);
+                            *reinterpret_cast<uint2*>(gi + k) = *reinterpret_cast<const uint2*>(bidx + k);
+                        }
                     }
                     break;
                 }
