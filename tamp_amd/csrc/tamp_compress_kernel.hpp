@@ -2248,8 +2248,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     const uintptr_t A0 = reinterpret_cast<uintptr_t>(P + c0) & ~(uintptr_t)3, A1 = reinterpret_cast<uintptr_t>(P + c1c - 1) & ~(uintptr_t)3;
                     const uint32_t ndw = (uint32_t)((A1 - A0) >> 2) + 1;
                     for (uint32_t j = tid; j < ndw; j += nt) {
-                        uint32_t* const dst = reinterpret_cast<uint32_t*>(A0 + 4 * (uintptr_t)j);
-                        const int32_t i0 = (int32_t)(reinterpret_cast<intptr_t>(dst) - reinterpret_cast<intptr_t>(P));  // ob index of its first byte
+                        // (an explicitly GLOBAL pointer: built from an integer it would be a generic one, and the store / atomic FLAT)
+                        typedef __attribute__((address_space(1))) uint32_t GlobalWord;
+                        GlobalWord* const dst = (GlobalWord*)(A0 + 4 * (uintptr_t)j);
+                        const int32_t i0 = (int32_t)((intptr_t)(A0 + 4 * (uintptr_t)j) - reinterpret_cast<intptr_t>(P));  // ob index of its first byte
                         uint32_t v = 0;
                         if (i0 >= (int32_t)c0 && i0 + 4 <= (int32_t)c1c) {
                             v = lds_u32_unaligned(ob, (uint32_t)i0);
@@ -2257,7 +2259,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             for (int32_t x = 0; x < 4; x++)
                                 if (i0 + x >= (int32_t)c0 && i0 + x < (int32_t)c1c) v |= (uint32_t)ob[i0 + x] << (8 * x);
                         }
-                        if (j == 0 || j == ndw - 1) atomicOr(dst, v);
+                        if (j == 0 || j == ndw - 1) __hip_atomic_fetch_or(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else *dst = v;
                     }
                 }
