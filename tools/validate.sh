@@ -1,7 +1,7 @@
 #!/bin/bash
 # Validation and evidence of a round on one MI355X box (repo root; results under gpurun_out/).
 #   bash tools/validate.sh fuzz  [SEED=50] [SCALE=1]   randomised differential runs against the reference C / oracle:
-#                                                      batch kernels, pieces, streaming scripts, both resume kernels, static grid
+#                                                      batch kernels, pieces, streaming scripts, both resume kernels, static grid, block mode
 #   TAG=r4 bash tools/validate.sh final                GPU test tier, smoke(), then the rocprofv3 passes of tools/pmc_run.sh
 # (one maintained script instead of the per-round one-offs of rounds 1-3)
 cd "${GRAFT_REPO_ROOT:?}"
@@ -15,6 +15,7 @@ if [ "$MODE" = fuzz ]; then
   run encres $((90 * K)) python tools/fuzz_encoder_resume_gpu.py
   run decres $((90 * K)) python tools/fuzz_resume_gpu.py
   TAMP_AMD_STATIC_GRID=1 run gpu_static $((60 * K)) python tools/fuzz_gpu.py
+  run block $((90 * K)) python tools/fuzz_block_gpu.py
   for f in $OUT/*.log; do echo "[$(basename $f .log)] $(grep -h 'fuzz\|rc=' $f | tail -2 | tr '\n' ' ')"; done | tee $OUT/summary.txt
 else
   TAG=${TAG:-r4}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
