@@ -96,6 +96,10 @@ struct DeviceCtx {
     // table words of the stream read back before the launch
     std::mutex blk_mu;
     HostPipe::Grow blk_scratch;
+    // expensive-first ordering: gathered tables, one buffer per HIP stream (launches on a stream are ordered, so the next
+    // launch's kernels find the previous one's done with it; a stream-ordered allocation per launch cost 0.7 ms of host time)
+    std::mutex lpt_mu;
+    std::map<hipStream_t, HostPipe::Grow> lpt_scratch;
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -230,6 +234,66 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     if (blk < 64) blk = 64;
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
     return blk;
+}
+
+// Expensive streams first (round 5).  One stream = one workgroup, so a batch cannot finish before its slowest stream does, and
+// a batch of only a few rounds of the persistent grid -- 3,052 streams per GPU when BASELINE configs[2] runs on eight -- waits
+// for whichever slow stream happened to start last.  What makes a stream slow are its lags and searches, and a
+// cheap proxy ranks them well: the number of ALIGNED DWORDS OF FOUR EQUAL BYTES (of the stand-in's 2,304 chunks the slowest
+// ones rank 0-7 of 768 by it on prose, 1-57 on Python sources).  Three tiny kernels around the compress launch: score per
+// stream, one-workgroup counting sort (descending), the batch's tables gathered in that order -- the compress kernel reads
+// row i of the gathered tables, so its claims ARE the order -- and sizes / statuses scattered back afterwards.
+__global__ void __launch_bounds__(256) tamp_stream_score_kernel(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                                                                 uint32_t n_streams, uint32_t* score) {
+    const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_streams) return;
+    const uint8_t* p = in + in_off[s];
+    const uint32_t n = in_len[s];
+    const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(p) & 3)) & 3);
+    uint32_t cnt = 0;
+    if (n > head + 4) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p + head);
+        const uint32_t nw = (n - head) >> 2;
+        for (uint32_t k = lane; k < nw; k += 64) {
+            const uint32_t d = w[k];
+            cnt += d == (d & 0xFFu) * 0x01010101u;
+        }
+    }
+    cnt = wave_scan_add(cnt);  // (inclusive scan: the last lane holds the sum)
+    if (lane == 63) score[s] = cnt;
+}
+__global__ void __launch_bounds__(1024) tamp_stream_order_kernel(const uint32_t* score, uint32_t n_streams, uint32_t* order) {
+    __shared__ uint32_t bins[1024];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_streams; s += 1024) atomicAdd(&bins[1023u - min(score[s], 1023u)], 1u);  // (descending)
+    __syncthreads();
+    // exclusive scan of the 1,024 bins: 16 wavefronts
+    const uint32_t v = bins[threadIdx.x];
+    const uint32_t incl = wave_scan_add(v);
+    __shared__ uint32_t wsum[16];
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
+    bins[threadIdx.x] = base + incl - v;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_streams; s += 1024) order[atomicAdd(&bins[1023u - min(score[s], 1023u)], 1u)] = s;
+}
+__global__ void tamp_gather_rows_kernel(const uint32_t* order, uint32_t n, const uint64_t* in_off, const uint32_t* in_len,
+                                        const uint64_t* out_off, const uint32_t* out_cap, uint64_t* g_in_off, uint32_t* g_in_len,
+                                        uint64_t* g_out_off, uint32_t* g_out_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = order[i];
+    g_in_off[i] = in_off[s], g_in_len[i] = in_len[s], g_out_off[i] = out_off[s], g_out_cap[i] = out_cap[s];
+}
+__global__ void tamp_scatter_results_kernel(const uint32_t* order, uint32_t n, const uint32_t* g_out_len, const int8_t* g_status,
+                                            uint32_t* out_len, int8_t* status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = order[i];
+    out_len[s] = g_out_len[i], status[s] = g_status[i];
 }
 
 // Block mode, pass 2: entry offset and bit position of every block from the tables of pass 1 -- a chain of one dependent
@@ -475,10 +539,50 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
         }
         // (every argument check lies in front of the event pair: a refused call leaves no half-recorded timing)
         timing_begin(st);
+        // expensive streams first, for batches of more than one and at most ~18 rounds of the grid (beyond, the tail is short
+        // next to the batch; TAMP_AMD_LPT=0 / =1 force it off / on)
+        bool lpt = threads == 256 && !seg && n_streams > g && n_streams <= 32768;
+        if (const char* e = getenv("TAMP_AMD_LPT")) lpt = atoi(e) != 0 && threads == 256 && !seg && n_streams > 1 && n_streams <= (1u << 20);
+        uint8_t* lpt_mem = nullptr;
+        uint32_t* lpt_order = nullptr;
+        uint32_t* lpt_out_len = nullptr;
+        int8_t* lpt_status = nullptr;
+        if (lpt) {
+            const size_t n = n_streams;
+            const size_t bytes = n * (4 + 4 + 8 + 4 + 8 + 4 + 4 + 1) + 256;
+            {
+                std::lock_guard<std::mutex> lock(ctx->lpt_mu);
+                DeviceCtx::HostPipe::Grow& gbuf = ctx->lpt_scratch[st];
+                if (gbuf.need(bytes) == hipSuccess) lpt_mem = static_cast<uint8_t*>(gbuf.p);
+            }
+            if (!lpt_mem) {
+                (void)hipGetLastError();
+                lpt = false;
+            } else {
+                uint64_t* g_in_off = reinterpret_cast<uint64_t*>(lpt_mem);
+                uint64_t* g_out_off = g_in_off + n;
+                uint32_t* score = reinterpret_cast<uint32_t*>(g_out_off + n);
+                lpt_order = score + n;
+                uint32_t* g_in_len = lpt_order + n;
+                uint32_t* g_out_cap = g_in_len + n;
+                lpt_out_len = g_out_cap + n;
+                lpt_status = reinterpret_cast<int8_t*>(lpt_out_len + n);
+                hipLaunchKernelGGL(tamp_stream_score_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, a.in, a.in_off, a.in_len, (uint32_t)n, score);
+                hipLaunchKernelGGL(tamp_stream_order_kernel, dim3(1), dim3(1024), 0, st, score, (uint32_t)n, lpt_order);
+                hipLaunchKernelGGL(tamp_gather_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, lpt_order, (uint32_t)n, a.in_off,
+                                   a.in_len, a.out_off, a.out_cap, g_in_off, g_in_len, g_out_off, g_out_cap);
+                a.in_off = g_in_off, a.in_len = g_in_len, a.out_off = g_out_off, a.out_cap = g_out_cap;
+                a.out_len = lpt_out_len, a.status = lpt_status;
+            }
+        }
         const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
         a.work_counter = ctx->work_counters + slot;
         HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(kernel, dim3((uint32_t)g), dim3(threads), L.total, st, a);
+        if (lpt) {
+            hipLaunchKernelGGL(tamp_scatter_results_kernel, dim3((uint32_t)((n_streams + 255) / 256)), dim3(256), 0, st, lpt_order,
+                               (uint32_t)n_streams, lpt_out_len, lpt_status, d_out_len, d_status);
+        }
     } else {
         timing_begin(st);
         const size_t launch_step = grid;
@@ -1315,6 +1419,14 @@ long long tamp_amd_trim(int device) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (slab.p) { (void)hipFree(slab.p); freed += (long long)slab.bytes; slab.p = nullptr, slab.bytes = 0; }
         if (slab.split) { (void)hipFree(slab.split); freed += (long long)slab.split_bytes; slab.split = nullptr, slab.split_bytes = 0; }
+    }
+    {   // block-mode tables and the expensive-first ordering's gathered tables (round 5)
+        std::lock_guard<std::mutex> blk_lock(ctx->blk_mu);
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        if (ctx->blk_scratch.p) { (void)hipFree(ctx->blk_scratch.p); freed += (long long)ctx->blk_scratch.bytes; ctx->blk_scratch.p = nullptr, ctx->blk_scratch.bytes = 0; }
+        std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
+        for (auto& kv : ctx->lpt_scratch)
+            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
     }
     {   // the host-memory pipeline: pinned staging of non-tiling output slabs (it grows with the largest extent ever staged,
         // possibly gigabytes of pinned RAM) and the device-side chunk buffers; both grow again on demand
