@@ -263,22 +263,50 @@ __global__ void __launch_bounds__(256) tamp_stream_score_kernel(const uint8_t* i
     if (lane == 63) score[s] = cnt;
 }
 __global__ void __launch_bounds__(1024) tamp_stream_order_kernel(const uint32_t* score, uint32_t n_streams, uint32_t* order) {
+    // counting sort by min(score, 1023), descending, one workgroup.  Lanes of a wavefront that hold the same bin go to the LDS
+    // counter together (one atomic per distinct bin and wavefront: a batch whose streams all score alike -- synthetic text:
+    // zero everywhere -- would otherwise queue 65,536 atomics on one word, 0.11 ms)
     __shared__ uint32_t bins[1024];
+    __shared__ uint32_t wsum[16];
     bins[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < n_streams; s += 1024) atomicAdd(&bins[1023u - min(score[s], 1023u)], 1u);  // (descending)
+    const uint32_t lane = threadIdx.x & 63;
+    auto grouped_add = [&](uint32_t bin, bool live) -> uint32_t {  // -> this lane's slot in its bin
+        uint32_t slot = 0;
+        uint64_t todo = __ballot(live);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)leader);
+            const uint64_t same = __ballot(live && bin == b) & todo;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&bins[b], (uint32_t)__builtin_popcountll(same));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+            if (live && bin == b) slot = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1));
+            todo &= ~same;
+        }
+        return slot;
+    };
+    const uint32_t rounds = (n_streams + 1023) / 1024;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t s = r * 1024 + threadIdx.x;
+        const bool live = s < n_streams;
+        (void)grouped_add(live ? 1023u - min(score[s], 1023u) : 0u, live);
+    }
     __syncthreads();
-    // exclusive scan of the 1,024 bins: 16 wavefronts
-    const uint32_t v = bins[threadIdx.x];
+    const uint32_t v = bins[threadIdx.x];  // exclusive scan of the 1,024 bins: 16 wavefronts
     const uint32_t incl = wave_scan_add(v);
-    __shared__ uint32_t wsum[16];
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
     bins[threadIdx.x] = base + incl - v;
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < n_streams; s += 1024) order[atomicAdd(&bins[1023u - min(score[s], 1023u)], 1u)] = s;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t s = r * 1024 + threadIdx.x;
+        const bool live = s < n_streams;
+        const uint32_t slot = grouped_add(live ? 1023u - min(score[s], 1023u) : 0u, live);
+        if (live) order[slot] = s;
+    }
 }
 __global__ void tamp_gather_rows_kernel(const uint32_t* order, uint32_t n, const uint64_t* in_off, const uint32_t* in_len,
                                         const uint64_t* out_off, const uint32_t* out_cap, uint64_t* g_in_off, uint32_t* g_in_len,
