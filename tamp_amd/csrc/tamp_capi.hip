@@ -95,7 +95,7 @@ struct DeviceCtx {
     // block mode (one long v1 stream over all workgroups): per-block tables of pass 1 / positions of pass 2, and the four
     // table words of the stream read back before the launch
     std::mutex blk_mu;
-    HostPipe::Grow blk_scratch;
+    std::map<hipStream_t, HostPipe::Grow> blk_scratch;  // (one per HIP stream: two calls in flight on two streams must not share tables)
     // expensive-first ordering: gathered tables, one buffer per HIP stream (launches on a stream are ordered, so the next
     // launch's kernels find the previous one's done with it; a stream-ordered allocation per launch cost 0.7 ms of host time)
     std::mutex lpt_mu;
@@ -407,11 +407,12 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     const size_t len_bytes = ((size_t)n + 1024 + 255) & ~(size_t)255;
     const bool keep_tables = (size_t)n * 3 <= ((size_t)3 << 29) && !getenv("TAMP_AMD_BLOCK_REMATCH");
     const size_t tables_bytes = keep_tables ? 3 * len_bytes : 0;
-    HIP_OK(ctx->blk_scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256 + tables_bytes));
-    a.blk_table = static_cast<uint32_t*>(ctx->blk_scratch.p);
-    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes);
-    uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes + info_bytes);
-    uint8_t* const tables = static_cast<uint8_t*>(ctx->blk_scratch.p) + table_bytes + info_bytes + (((size_t)n_chunks * 16 * 8 + 255) & ~(size_t)255);
+    DeviceCtx::HostPipe::Grow& scratch = ctx->blk_scratch[st];
+    HIP_OK(scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256 + tables_bytes));
+    a.blk_table = static_cast<uint32_t*>(scratch.p);
+    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(scratch.p) + table_bytes);
+    uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch.p) + table_bytes + info_bytes);
+    uint8_t* const tables = static_cast<uint8_t*>(scratch.p) + table_bytes + info_bytes + (((size_t)n_chunks * 16 * 8 + 255) & ~(size_t)255);
     a.blk_len = keep_tables ? tables : nullptr;
     a.blk_idx = keep_tables ? reinterpret_cast<uint16_t*>(tables + len_bytes) : nullptr;
     a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
@@ -1451,7 +1452,8 @@ long long tamp_amd_trim(int device) {
     {   // block-mode tables and the expensive-first ordering's gathered tables (round 5)
         std::lock_guard<std::mutex> blk_lock(ctx->blk_mu);
         if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
-        if (ctx->blk_scratch.p) { (void)hipFree(ctx->blk_scratch.p); freed += (long long)ctx->blk_scratch.bytes; ctx->blk_scratch.p = nullptr, ctx->blk_scratch.bytes = 0; }
+        for (auto& kv : ctx->blk_scratch)
+            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
         std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
         for (auto& kv : ctx->lpt_scratch)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }

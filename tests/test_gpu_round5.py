@@ -238,3 +238,24 @@ def test_expensive_streams_first_changes_the_schedule_not_the_results(ta, checke
     # pinned elsewhere -- tests/test_gpu_parity.py::test_restricted_output)
     assert (res["1"][1] == wantr.status).all()
     assert all(res["1"][0][i] == wantr.stream(i) for i in range(len(lens)) if wantr.status[i] == 0 and i % 5 == 0)
+
+
+def test_block_mode_calls_in_flight_on_two_streams_keep_their_own_tables(ta, checker):
+    """Two long v1 streams compressed on two HIP streams without a wait in between: every call's per-block tables live in a
+    scratch buffer of ITS stream (a shared one would be overwritten by the second call while the first still runs)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    a, b = _text(3_000_001, "prose"), _text(2_500_003, "python")
+    wa, wb = (_want(checker, x, window=10, literal=8, extended=False) for x in (a, b))
+    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(3):
+        for d, st in ((da, s1), (db, s2)):
+            res.append(ta.compress_batch(d, torch.zeros(1, dtype=torch.int64, device=dev), torch.tensor([d.numel()], dtype=torch.int32, device=dev),
+                                         window=10, literal=8, extended=False, max_in_len=int(d.numel()), stream=st.cuda_stream))
+    torch.cuda.synchronize()
+    for i, r in enumerate(res):
+        assert r.stream(0) == (wa if i % 2 == 0 else wb), i
