@@ -396,9 +396,10 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     HIP_OK(hipStreamSynchronize(st));
     const uint32_t n = row.in_len;
     if (n < min_len) return 1;
-    a.blk = pick_block(W, 0, true, false, false);
+    const bool runs_build = !getenv("TAMP_AMD_BLOCK_LEAN");  // (the run-aware build, as for every long stream; tuning: the lean one)
+    a.blk = pick_block(W, 0, true, false, runs_build);
     if (a.blk > 1024) a.blk = 1024;  // (more, smaller blocks: the unit of parallelism here)
-    const CompressLds L(W, a.blk, true, false, false);
+    const CompressLds L(W, a.blk, true, false, runs_build);
     if (L.total > ctx->lds_per_block) return 1;
     const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
     const uint32_t n_chunks = (n_blocks + kScanChunk - 1) / kScanChunk;
@@ -416,7 +417,9 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     a.blk_len = keep_tables ? tables : nullptr;
     a.blk_idx = keep_tables ? reinterpret_cast<uint16_t*>(tables + len_bytes) : nullptr;
     a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
-    auto kernel = tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>;
+    auto kernel = !runs_build ? tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>
+                  : conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHashBits, true, true>
+                                       : tamp_compress_kernel<true, false, true, 0, kHashBits, true, true>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, L.total));

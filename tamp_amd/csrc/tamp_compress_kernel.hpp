@@ -864,7 +864,7 @@ __device__ __forceinline__ T* as_global(T* p) {
 // tools/c-profiler/main.c:52-54), which one workgroup takes 6 s for.
 template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false, bool BLOCKM = false>
 __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) tamp_compress_kernel(CompressArgs a_k) {
-    static_assert(!BLOCKM || (LOOP && PACKED && !LAZY && !RUNS), "block mode: the lean persistent build");
+    static_assert(!BLOCKM || (LOOP && PACKED && !LAZY), "block mode: a persistent build of the default parse");
     // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
