@@ -380,43 +380,33 @@ __global__ void __launch_bounds__(256) tamp_block_scan_kernel(const uint32_t* ta
 
 // Block mode (tamp_compress_kernel<.., BLOCKM>): ONE long stream of the v1 format, literal 8, default parse, fresh window.
 // -> TAMP_OK when the stream was taken this way, 1 when the call does not qualify (the caller goes on with the batch kernel).
-int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* conf, uint32_t max_in_len, hipStream_t st) {
+int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a0, const TampAmdConf* conf, uint32_t max_in_len, hipStream_t st, size_t n_streams) {
     const uint32_t W = 1u << conf->window;
     uint32_t min_len = 256u << 10;
     if (const char* e = getenv("TAMP_AMD_BLOCK_MIN")) min_len = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;  // (tuning / tests; 0 = off)
-    if (conf->extended || conf->lazy_matching || conf->literal != 8 || conf->window > 14 || a.state || a.seg_flags || max_in_len < min_len)
+    if (conf->extended || conf->lazy_matching || conf->literal != 8 || conf->window > 14 || a0.state || a0.seg_flags || max_in_len < min_len ||
+        n_streams == 0 || n_streams > 64)
         return 1;
     std::lock_guard<std::mutex> lock(ctx->blk_mu);
-    // the stream's table row: length, capacity (the launch geometry and the zero fill depend on them)
-    struct Row { uint64_t in_off, out_off; uint32_t in_len, out_cap; } row;
-    HIP_OK(hipMemcpyAsync(&row.in_off, a.in_off, 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&row.out_off, a.out_off, 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&row.in_len, a.in_len, 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&row.out_cap, a.out_cap, 4, hipMemcpyDeviceToHost, st));
+    // the streams' table rows: lengths, capacities (the launch geometry and the zero fill depend on them); a handful of LONG
+    // streams is taken one after the other, each over all workgroups -- any shorter one among them and the batch kernel takes all
+    uint64_t in_off[64], out_off[64];
+    uint32_t in_len[64], out_cap[64];
+    HIP_OK(hipMemcpyAsync(in_off, a0.in_off, 8 * n_streams, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_off, a0.out_off, 8 * n_streams, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(in_len, a0.in_len, 4 * n_streams, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_cap, a0.out_cap, 4 * n_streams, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    const uint32_t n = row.in_len;
-    if (n < min_len) return 1;
+    uint32_t n_max = 0;
+    for (size_t i = 0; i < n_streams; i++) {
+        if (in_len[i] < min_len) return 1;
+        n_max = std::max(n_max, in_len[i]);
+    }
     const bool runs_build = !getenv("TAMP_AMD_BLOCK_LEAN");  // (the run-aware build, as for every long stream; tuning: the lean one)
-    a.blk = pick_block(W, 0, true, false, runs_build);
-    if (a.blk > 1024) a.blk = 1024;  // (more, smaller blocks: the unit of parallelism here)
-    const CompressLds L(W, a.blk, true, false, runs_build);
+    a0.blk = pick_block(W, 0, true, false, runs_build);
+    if (a0.blk > 1024) a0.blk = 1024;  // (more, smaller blocks: the unit of parallelism here)
+    const CompressLds L(W, a0.blk, true, false, runs_build);
     if (L.total > ctx->lds_per_block) return 1;
-    const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
-    const uint32_t n_chunks = (n_blocks + kScanChunk - 1) / kScanChunk;
-    const size_t table_bytes = ((size_t)n_blocks * 16 * 4 + 255) & ~(size_t)255, info_bytes = ((size_t)n_blocks * 8 + 255) & ~(size_t)255;
-    // (the match results of pass 1, 3 bytes per input byte, when that stays under 1.5 GiB: pass 3 then does not match again)
-    const size_t len_bytes = ((size_t)n + 1024 + 255) & ~(size_t)255;
-    const bool keep_tables = (size_t)n * 3 <= ((size_t)3 << 29) && !getenv("TAMP_AMD_BLOCK_REMATCH");
-    const size_t tables_bytes = keep_tables ? 3 * len_bytes : 0;
-    DeviceCtx::HostPipe::Grow& scratch = ctx->blk_scratch[st];
-    HIP_OK(scratch.need(table_bytes + info_bytes + (size_t)n_chunks * 16 * 8 + 256 + tables_bytes));
-    a.blk_table = static_cast<uint32_t*>(scratch.p);
-    a.blk_info = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(scratch.p) + table_bytes);
-    uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch.p) + table_bytes + info_bytes);
-    uint8_t* const tables = static_cast<uint8_t*>(scratch.p) + table_bytes + info_bytes + (((size_t)n_chunks * 16 * 8 + 255) & ~(size_t)255);
-    a.blk_len = keep_tables ? tables : nullptr;
-    a.blk_idx = keep_tables ? reinterpret_cast<uint16_t*>(tables + len_bytes) : nullptr;
-    a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
     auto kernel = !runs_build ? tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>
                   : conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHashBits, true, true>
                                        : tamp_compress_kernel<true, false, true, 0, kHashBits, true, true>;
@@ -424,22 +414,46 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a, const TampAmdConf* co
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, L.total));
     if (per_cu < 1) per_cu = 1;
-    const uint32_t g = (uint32_t)std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, n_blocks);
+    // scratch for the longest of them
+    const uint32_t nb_max = (n_max + a0.blk - 1) / a0.blk, nc_max = (nb_max + kScanChunk - 1) / kScanChunk;
+    const size_t table_bytes = ((size_t)nb_max * 16 * 4 + 255) & ~(size_t)255, info_bytes = ((size_t)nb_max * 8 + 255) & ~(size_t)255;
+    const size_t chunk_bytes = ((size_t)nc_max * 16 * 8 + 255) & ~(size_t)255;
+    // (the match results of pass 1, 3 bytes per input byte, when that stays under 1.5 GiB: pass 3 then does not match again)
+    const size_t len_bytes = ((size_t)n_max + 1024 + 255) & ~(size_t)255;
+    const bool keep_tables = (size_t)n_max * 3 <= ((size_t)3 << 29) && !getenv("TAMP_AMD_BLOCK_REMATCH");
+    DeviceCtx::HostPipe::Grow& scratch = ctx->blk_scratch[st];
+    HIP_OK(scratch.need(table_bytes + info_bytes + chunk_bytes + 256 + (keep_tables ? 3 * len_bytes : 0)));
+    uint8_t* const base = static_cast<uint8_t*>(scratch.p);
+    uint32_t* const chunk_table = reinterpret_cast<uint32_t*>(base + table_bytes + info_bytes);
+    uint8_t* const tables = base + table_bytes + info_bytes + chunk_bytes;
     timing_begin(st);
-    // every byte the emitters may OR into: header + 9 bits per input byte at most (all literals), capped by the caller's room
-    const uint64_t bound = (uint64_t)a.nlead + ((uint64_t)n * 9 + 7) / 8 + 8;
-    HIP_OK(hipMemsetAsync(a.out + row.out_off, 0, (size_t)std::min<uint64_t>(bound, row.out_cap), st));
-    for (uint32_t pass = 1; pass <= 3; pass++) {
-        if (pass == 2) {
-            hipLaunchKernelGGL(tamp_block_scan_chunks, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, n_blocks);
-            hipLaunchKernelGGL(tamp_block_scan_kernel, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, a.blk_info, n_blocks, 8u * a.nlead);
-            continue;
+    for (size_t i = 0; i < n_streams; i++) {
+        CompressArgs a = a0;
+        a.in_off += i, a.in_len += i, a.out_off += i, a.out_cap += i, a.out_len += i, a.status += i;  // (the kernel reads row 0)
+        const uint32_t n = in_len[i];
+        const uint32_t n_blocks = (n + a.blk - 1) / a.blk;
+        const uint32_t n_chunks = (n_blocks + kScanChunk - 1) / kScanChunk;
+        a.blk_table = reinterpret_cast<uint32_t*>(base);
+        a.blk_info = reinterpret_cast<unsigned long long*>(base + table_bytes);
+        a.blk_len = keep_tables ? tables : nullptr;
+        a.blk_idx = keep_tables ? reinterpret_cast<uint16_t*>(tables + len_bytes) : nullptr;
+        a.n_blocks = n_blocks, a.n_streams = n_blocks, a.first_stream = 0, a.claim = 1, a.cut_run = 0;
+        const uint32_t g = (uint32_t)std::min<size_t>((size_t)per_cu * (size_t)ctx->cu_count, n_blocks);
+        // every byte the emitters may OR into: header + 9 bits per input byte at most (all literals), capped by the caller's room
+        const uint64_t bound = (uint64_t)a.nlead + ((uint64_t)n * 9 + 7) / 8 + 8;
+        HIP_OK(hipMemsetAsync(a.out + out_off[i], 0, (size_t)std::min<uint64_t>(bound, out_cap[i]), st));
+        for (uint32_t pass = 1; pass <= 3; pass++) {
+            if (pass == 2) {
+                hipLaunchKernelGGL(tamp_block_scan_chunks, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, n_blocks);
+                hipLaunchKernelGGL(tamp_block_scan_kernel, dim3(n_chunks), dim3(256), 0, st, a.blk_table, chunk_table, a.blk_info, n_blocks, 8u * a.nlead);
+                continue;
+            }
+            const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
+            a.work_counter = ctx->work_counters + slot;
+            a.block_pass = pass;
+            HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(256), L.total, st, a);
         }
-        const uint32_t slot = ctx->next_counter.fetch_add(1) % DeviceCtx::kCounters;
-        a.work_counter = ctx->work_counters + slot;
-        a.block_pass = pass;
-        HIP_OK(hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(256), L.total, st, a);
     }
     timing_end(st);
     HIP_OK(hipGetLastError());
@@ -484,8 +498,8 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     if (const char* e = getenv("TAMP_AMD_CUT_RUN")) { const int v = atoi(e); a.cut_run = (conf->extended && v >= 2 && v <= 64) ? (uint32_t)v : 0u; }
     a.dbg = getenv("TAMP_AMD_DBG") ? (uint32_t)atoi(getenv("TAMP_AMD_DBG")) : 0;
     a.blk_table = nullptr, a.blk_info = nullptr, a.block_pass = 0, a.n_blocks = 0, a.blk_len = nullptr, a.blk_idx = nullptr;
-    if (n_streams == 1 && !seg) {  // ONE long v1 stream: its blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>)
-        const int rc = launch_compress_blocks(ctx, a, conf, max_in_len, st);
+    if (n_streams <= 64 && !seg) {  // a handful of LONG v1 streams: each one's blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>)
+        const int rc = launch_compress_blocks(ctx, a, conf, max_in_len, st, n_streams);
         if (rc != 1) return rc;
     }
     const uint32_t W = 1u << conf->window;

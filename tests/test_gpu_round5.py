@@ -259,3 +259,16 @@ def test_block_mode_calls_in_flight_on_two_streams_keep_their_own_tables(ta, che
     torch.cuda.synchronize()
     for i, r in enumerate(res):
         assert r.stream(0) == (wa if i % 2 == 0 else wb), i
+
+
+def test_a_handful_of_long_v1_streams_take_block_mode_one_after_the_other(ta, checker):
+    """Up to 64 streams per call, every one of them 256 KiB or more: each is spread over all workgroups in turn (one call,
+    no batch of one-workgroup streams); with a short one among them the batch kernel takes the whole call.  Same bytes."""
+    parts = [_text(n, k) for n, k in ((300_000, "prose"), (1_234_567, "python"), (262_144, "synth"), (700_001, "markup"))]
+    want = [_want(checker, p, window=10, literal=8, extended=False) for p in parts]
+    got = ta.compress_batch([p.tobytes() for p in parts], window=10, literal=8, extended=False)
+    assert [int(x) for x in got.status] == [0] * 4 and [got.stream(i) for i in range(4)] == want
+    mixed = parts + [_text(5000, "prose")]
+    want.append(_want(checker, mixed[-1], window=10, literal=8, extended=False))
+    got = ta.compress_batch([p.tobytes() for p in mixed], window=10, literal=8, extended=False)
+    assert [got.stream(i) for i in range(5)] == want
