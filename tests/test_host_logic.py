@@ -426,3 +426,19 @@ def test_import_tamp_resolves_to_this_package():
     for name in ("compress", "decompress", "Compressor", "Decompressor", "TextCompressor", "TextDecompressor", "open",
                  "initialize_dictionary", "compute_min_pattern_size", "bit_size", "ExcessBitsError"):
         assert getattr(tamp, name) is getattr(tamp_amd, name), name
+
+
+def test_bench_flags_of_round_5_exist_and_the_probe_is_opt_in():
+    """`bench.py --help` (no GPU needed): the corpus probe and the download are opt-in flags, the configs[2] stand-in and the
+    shard fraction are there."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    for flag in ("--probe-corpus", "--fetch-corpus", "--corpus-standin", "--shard-fraction", "--corpus"):
+        assert flag in out.stdout, flag
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "wl.probe_corpus(env={}, fetch=(args.fetch_corpus and rank == 0))" in src  # (never without --probe-corpus, never fetching by default)
