@@ -306,7 +306,10 @@ __global__ void __launch_bounds__(256) tamp_decompress_resume_kernel(ResumeArgs 
                     if (!rle) {
                         fetch();
                         settle_mark();
-                        if (8 * ip_ref - T < wbits) mark_refill();  // the reference refills only when it runs short
+                        if (8 * ip_ref - T < wbits) {  // the reference refills only when it runs short, and by then it
+                            mark_refill();             // has parked the size (:215-222): an out-of-bounds offset
+                            ts = kTokExtHaveSize, pend_size = count;  // leaves the object in that state
+                        }
                         if (bits_left() < wbits) {  // size known, offset still to come (:215-222)
                             ts = kTokExtHaveSize, pend_size = count;
                             marked = false;

@@ -835,7 +835,7 @@ def test_decoder_resume_golden_scripts(ta):
     """Decoder objects advanced call by call on the device (tamp_batch_decompress_resume) against what one reference
     TampDecompressor returned for the same calls (tests/golden/decoder_resume.json): status, bytes and consumed count
     of every call -- tokens cut short by a full output buffer, by the end of the input, headers split over calls."""
-    recs = load_golden("decoder_resume.json")
+    recs = load_golden("decoder_resume.json") + load_golden("decoder_resume_fuzz.json")
     groups = {}
     for rec in recs:
         data, script, conf, dic, want = _resume_golden(rec)

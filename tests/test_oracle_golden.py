@@ -123,6 +123,7 @@ def test_decoder_resume_scripts(oracle):
     tests/test_decompressor.py:99-144, ctests/test_decompressor.c:105-144)."""
     recs = load_golden("decoder_resume.json")
     assert len(recs) >= 50
+    recs = recs + load_golden("decoder_resume_fuzz.json")  # objects a randomised GPU run once got wrong (calls after an error)
     for rec in recs:
         data, script, conf, dic, want = _resume_record(rec)
         r0, calls = oracle.decode_script(data, script, conf=conf, window_bits=rec["window_bits"], dictionary=dic)

@@ -1,6 +1,7 @@
 """Randomised write / flush scripts on tamp_amd.Compressor with every write handed over as a piece (PIECE_MIN = 1), against a
 live reference object (oracle/_ref): the stream must be the reference's at every flush point and at the end, the running
-byte count within four bytes of it in between (the reference's object holds its last token's bits back).
+byte count at most eight bytes ahead of it in between (the reference's object holds back the bits of its last token, <= 4 bytes,
+and in the extended format a run / extended match it has not closed yet, <= 35 bits more; 5 was seen once in 5,000 scripts).
 usage: python tools/fuzz_pieces_gpu.py [seconds]   (GPU box)"""
 import io, os, random, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
@@ -65,7 +66,7 @@ while time.time() - t0 < budget:
     gc, wc = np.cumsum(got_counts), np.cumsum(want_counts)
     for i, op in enumerate(ops):
         d = int(gc[i] - wc[i])
-        if (op[0] == "write" and not 0 <= d <= 4) or (op[0] != "write" and d != 0):
+        if (op[0] == "write" and not 0 <= d <= 8) or (op[0] != "write" and d != 0):
             print("COUNT MISMATCH", scripts, i, op[0], d); sys.exit(1)
     scripts += 1
 print(f"fuzz_pieces: {scripts} scripts, {calls} calls, all equal to the reference object ({time.time()-t0:.0f} s)")
