@@ -1910,6 +1910,15 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #endif
                 };
                 for (;;) {
+                    // (round 5: the walk's scalars are changed inside `if (wave == 0)` -- a divergent branch to the compiler --
+                    // and come round the epoch loop as vector values: the hop loop and most of the state machine were
+                    // v_cmp + s_and_saveexec + s_cbranch_execz on VGPR copies.  Pinned back to SGPRs once per iteration:
+                    // 1.5 k -> 1.35 k VALU in the step's code, the hop loop 5 VALU + 1 LDS read a hop instead of 12 + three
+                    // exec-mask regions; synthetic -0.9 %, prose -1.8 %, markup -2.7 %, Python sources -1 %.  Deriving `wave`
+                    // itself from the scalar copy frees the branch as well but costs 33 more spilled SGPRs: no better.)
+                    wk.ntok = Walk::uni(wk.ntok), wk.ns = Walk::uni(wk.ns), wk.rd = Walk::uni(wk.rd), wk.wr = Walk::uni(wk.wr);
+                    wk.rle_count = Walk::uni(wk.rle_count), wk.ext_count = Walk::uni(wk.ext_count), wk.ext_pos = Walk::uni(wk.ext_pos);
+                    nqueued = Walk::uni(nqueued), wk.wp_e = Walk::uni(wk.wp_e), w_p0 = Walk::uni(w_p0), wk.nvalid = Walk::uni(wk.nvalid);
                     if (wk.ntok + 72 > L.tokcap || wk.ns + 8 > kSlowCap) {
                         act = kActContinue;
                         break;
@@ -2100,8 +2109,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #endif
             asm volatile("" : "+v"(tid));
             lane = (int)(tid & (kWave - 1)), wave = tid >> 6, wk.lane = lane;  // (re-derived: see above)
-            uint32_t act = ctl[cAct];
-            const uint32_t ntok = ctl[cNtok];
+            uint32_t act = Walk::uni(ctl[cAct]);
+            const uint32_t ntok = Walk::uni(ctl[cNtok]);
             const uint32_t K = (ntok + nt - 1) >> nt_log2;
             const uint32_t k0 = min(tid * K, ntok), k1 = min(k0 + K, ntok);
             auto token = [&](uint32_t k, uint32_t& v, uint32_t& nb) -> bool {  // false: literal with excess bits
@@ -2310,11 +2319,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
             TAMP_PROF_MARK(4);
             need_match = act == kActRebase;
             if (act == kActRebase) {
-                const uint32_t shift = ctl[cShift];
-                e_p0 = ctl[cP0];
-                e_pending = ctl[cPending];
-                e_wp = ctl[cWp];
-                cur_blk = ctl[cBlk];
+                const uint32_t shift = Walk::uni(ctl[cShift]);
+                e_p0 = Walk::uni(ctl[cP0]);
+                e_pending = Walk::uni(ctl[cPending]);
+                e_wp = Walk::uni(ctl[cWp]);
+                cur_blk = Walk::uni(ctl[cBlk]);
                 // re-base: ebuf[0..W) <- ebuf[shift..shift+W) (moving left, chunked)
                 if (shift) {
                     for (uint32_t base = 0; base < W; base += nt * 4) {
