@@ -460,9 +460,11 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
     const DecompressArgs& a = sa.d;
     static_assert(NT == 256 || NT == 64, "a workgroup or a wavefront per stream");
     static_assert(BPT == 16 || BPT == 8 || BPT == 4 || BPT == 2 || BPT == 1, "marks are read as one aligned group");
-    const uint32_t k = NT == 256 ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (the wavefront's number through v_readfirstlane: what follows from it -- the stream's record count, window, lags, sizes --
+    // is then scalar to the compiler for the wavefront-per-stream build as well, instead of vector loads and exec-mask loops)
+    const uint32_t k = NT == 256 ? blockIdx.x : blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (NT == 64 && k >= sa.count) return;  // (whole wavefronts: no workgroup barrier below)
-    uint8_t* const smem = NT == 256 ? smem_all : smem_all + (threadIdx.x >> 6) * split_resolve_lds(sa.maxcap);
+    uint8_t* const smem = NT == 256 ? smem_all : smem_all + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * split_resolve_lds(sa.maxcap);
     auto sync = [&]() {
         if constexpr (NT == 256) {
             __syncthreads();
