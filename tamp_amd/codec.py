@@ -367,8 +367,20 @@ class TextDecompressor(Decompressor):
 
 
 def decompress(data: bytes, *args, **kwargs) -> bytearray:
-    """``tamp.decompress`` (tamp/_c_decompressor.pyx:184-187)."""
-    with BytesIO(bytes(data)) as f:
+    """``tamp.decompress`` (tamp/_c_decompressor.pyx:184-187).
+
+    A whole v1 stream of ``ONE_SHOT_BLOCK_MIN`` bytes and more goes to the batch decoder as a batch of one, where the
+    library decodes ONE long stream with the whole device; everything else -- and whatever that call does
+    not finish with the normal end-of-input status -- takes the decoder object below."""
+    blob = bytes(data)
+    if len(blob) >= ONE_SHOT_BLOCK_MIN and not args and set(kwargs) <= {"dictionary"} and (blob[0] & 3) == 0:
+        from .batch import decompress_batch
+        # (room for the worst case at once -- a v1 match token of 2 + 8 bits yields up to 15 bytes: a call that runs out of room
+        # would take the one-wavefront decoder to find that out)
+        r = decompress_batch([blob], out_cap=12 * len(blob) + 64, dictionary=kwargs.get("dictionary"))
+        if int(r.status[0]) == _lib.INPUT_EXHAUSTED:
+            return bytearray(r.stream(0))
+    with BytesIO(blob) as f:
         d = Decompressor(f, *args, **kwargs)
         return d.read()
 

@@ -25,6 +25,7 @@
 #include "tamp_compress_kernel.hpp"
 #include "tamp_decompress_kernel.hpp"
 #include "tamp_decompress_split_kernel.hpp"
+#include "tamp_decompress_long_kernel.hpp"
 #include "tamp_decompress_wave_kernel.hpp"
 #include "tamp_decompress_resume_kernel.hpp"
 #include "tamp_compress_resume_kernel.hpp"
@@ -98,6 +99,8 @@ struct DeviceCtx {
     std::map<hipStream_t, HostPipe::Grow> blk_scratch;  // (one per HIP stream: two calls in flight on two streams must not share tables)
     // expensive-first ordering: gathered tables, one buffer per HIP stream (launches on a stream are ordered, so the next
     // launch's kernels find the previous one's done with it; a stream-ordered allocation per launch cost 0.7 ms of host time)
+    std::mutex long_mu;
+    std::map<hipStream_t, HostPipe::Grow> long_scratch;  // one long stream decoded by the whole device: chunk tables, records
     std::mutex lpt_mu;
     std::map<hipStream_t, HostPipe::Grow> lpt_scratch;
 };
@@ -692,11 +695,190 @@ __global__ void tamp_header_scan_kernel(const uint8_t* in, const uint64_t* in_of
     }
 }
 
+// ONE long v1 stream (tamp_decompress_long_kernel.hpp): start positions settled by rounds of a lane per 512 compressed bytes,
+// records per chunk, then the split decoder's RESOLVE over groups of at most kSplitMaxOut output bytes, in order, each with the
+// W bytes in front of it as its dictionary.  -> 1 when the call is not one (or anything is off: the exact decoders take it),
+// TAMP_OK when the stream has been decoded, an error code otherwise.  Nothing is written before the fall-back decision.
+int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
+                           const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
+                           const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed, hipStream_t st) {
+    if (const char* e = getenv("TAMP_AMD_LONGDEC")) { if (atoi(e) == 0) return 1; }
+    if (getenv("TAMP_AMD_DECODER")) return 1;
+    uint32_t min_len = 256u << 10;
+    if (const char* e = getenv("TAMP_AMD_LONGDEC_MIN")) { const long v = atol(e); if (v >= 64) min_len = (uint32_t)v; }
+    uint64_t in_off = 0, out_off = 0;
+    uint32_t n = 0, cap = 0;
+    HIP_OK(hipMemcpyAsync(&n, d_in_len, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (n < min_len || n > kMaxDecodeIn) return 1;
+    HIP_OK(hipMemcpyAsync(&in_off, d_in_off, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&out_off, d_out_off, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&cap, d_out_cap, 4, hipMemcpyDeviceToHost, st));
+    uint8_t hdr[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(hdr, d_in + in_off, 2, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const uint8_t* const in = d_in + in_off;
+    uint8_t* const out = d_out + out_off;
+    const uint32_t h0 = hdr[0], hs = 1 + (h0 & 1);
+    const uint32_t wbits = ((h0 >> 5) & 7) + 8, lbits = ((h0 >> 3) & 3) + 5;
+    const bool custom = (h0 >> 2) & 1, extended = (h0 >> 1) & 1, dreset = h0 & 1;
+    if (extended || dreset || (hs == 2 && hdr[1]) || wbits > (uint32_t)(max_wbits & 0x7F) || (max_wbits & 0x7F) > 15) return 1;
+    const uint32_t W = 1u << wbits;
+    if (custom && (!d_dict || dict_len < W)) return 1;
+    const uint8_t* const dict0 = custom ? d_dict : ctx->seed_dicts + ((size_t)2 << 15);  // (v1: the literal >= 7 table, decompressor.c:318-319)
+
+    const uint64_t total_bits = 8ull * n;
+    const uint32_t N = (uint32_t)((total_bits + kLongChunkBits - 1) / kLongChunkBits);
+    // scratch: g, g_next (N + 1 each), flags (4), ntok, outb, tokbase, rot (N each), then what the groups need
+    const size_t b_tab = ((size_t)(6 * (size_t)N + 16) * 4 + 255) & ~(size_t)255;
+    uint8_t* tab = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->long_mu);
+        DeviceCtx::HostPipe::Grow& gb = ctx->long_scratch[st];
+        // worst case records: the shortest token is a literal, 1 + literal bits
+        const size_t max_tok = (size_t)(total_bits / (1 + lbits)) + 4096;
+        const size_t b_groups = ((size_t)(max_tok / 256 + N + 64) * 16 + 255) & ~(size_t)255;
+        const size_t bytes = b_tab + max_tok * 4 + b_groups + 4 * (size_t)(1u << 15) + 4096;
+        if (gb.need(bytes) != hipSuccess) return 1;
+        tab = static_cast<uint8_t*>(gb.p);
+    }
+    uint32_t* const g0 = reinterpret_cast<uint32_t*>(tab);
+    uint32_t* const g1 = g0 + (N + 1);
+    uint32_t* const flags = g1 + (N + 1);
+    uint32_t* const d_ntok = flags + 8;
+    uint32_t* const d_outb = d_ntok + N;
+    uint32_t* const d_tokbase = d_outb + N;
+    uint32_t* const d_rot = d_tokbase + N;
+    uint32_t* const recs = reinterpret_cast<uint32_t*>(tab + b_tab);
+
+    timing_begin(st);
+    LongArgs la;
+    la.in = in, la.n = n, la.first_bit = 8 * hs, la.n_chunks = N, la.wbits = wbits, la.lbits = lbits;
+    la.flags = flags, la.ntok = d_ntok, la.outb = d_outb, la.tokbase = d_tokbase, la.rot = d_rot, la.recs = recs, la.write = 0;
+    // start guesses: the chunk boundaries themselves (chunk 0: behind the header)
+    {
+        std::vector<uint32_t> init(N + 1);
+        for (uint32_t i = 0; i <= N; i++) init[i] = i * kLongChunkBits;
+        init[0] = 8 * hs;
+        HIP_OK(hipMemcpyAsync(g0, init.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    const uint32_t lg = (N + 63) / 64;
+    uint32_t* cur = g0;
+    uint32_t* nxt = g1;
+    bool settled = false;
+    int rounds = 0;
+    for (int round = 0; round < 512 && !settled; round++, rounds++) {
+        HIP_OK(hipMemsetAsync(flags, 0, 8, st));
+        la.g = cur, la.g_next = nxt;
+        hipLaunchKernelGGL(tamp_long_sync_kernel, dim3(lg), dim3(64), 0, st, la);
+        uint32_t changed = 1;
+        HIP_OK(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::swap(cur, nxt);
+        settled = changed == 0;
+    }
+    const bool dbg_long = getenv("TAMP_AMD_LONGDEC_DEBUG") != nullptr;
+    if (dbg_long) fprintf(stderr, "[tamp_amd long decode] %u bytes, %u chunks, %d sync rounds, settled %d\n", n, N, rounds, (int)settled);
+    if (!settled) { timing_end(st); return 1; }
+    la.g = cur, la.g_next = nullptr, la.write = 0;
+    HIP_OK(hipMemsetAsync(flags, 0, 8, st));
+    hipLaunchKernelGGL(tamp_long_parse_kernel, dim3(lg), dim3(64), 0, st, la);
+    std::vector<uint32_t> ntok(N), outb(N);
+    uint32_t fl[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(ntok.data(), d_ntok, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(outb.data(), d_outb, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(fl, flags, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (fl[1]) { timing_end(st); return 1; }  // an out-of-bounds offset: the exact decoder reports where
+    // groups of whole chunks: at most kSplitMaxOut output bytes and 2^20 - 1 records each
+    struct Group { uint64_t v0; uint32_t tok0, ntok, nout; };
+    std::vector<Group> groups;
+    std::vector<uint32_t> tokbase(N), rot(N);
+    uint64_t v = 0, tk = 0;
+    {
+        Group gcur{0, 0, 0, 0};
+        for (uint32_t i = 0; i < N; i++) {
+            if (gcur.nout + outb[i] > kSplitMaxOut || gcur.ntok + ntok[i] > 0xFFFFFu) {
+                groups.push_back(gcur);
+                gcur = Group{v, (uint32_t)tk, 0, 0};
+            }
+            tokbase[i] = (uint32_t)tk, rot[i] = (uint32_t)(gcur.v0 & (W - 1));
+            gcur.ntok += ntok[i], gcur.nout += outb[i];
+            tk += ntok[i], v += outb[i];
+        }
+        groups.push_back(gcur);
+    }
+    // (room that is used up -- even exactly -- is TAMP_OUTPUT_FULL in the reference when padding bits are left, decompressor.c:431-436,
+    // and a partial last token when it is not enough: the exact decoder's)
+    if (v >= cap || tk > 0xFFFFFFFFull - 4096) { timing_end(st); return 1; }
+    HIP_OK(hipMemcpyAsync(d_tokbase, tokbase.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_rot, rot.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+    la.write = 1;
+    hipLaunchKernelGGL(tamp_long_parse_kernel, dim3(lg), dim3(64), 0, st, la);
+    // per group: meta word, output offset and size, in tables behind the records
+    const size_t G = groups.size();
+    uint8_t* const gtab = reinterpret_cast<uint8_t*>(recs) + (((size_t)tk + 4096) * 4 + 255 & ~(size_t)255);
+    uint64_t* const d_goff = reinterpret_cast<uint64_t*>(gtab);
+    uint32_t* const d_glen = reinterpret_cast<uint32_t*>(d_goff + G);
+    uint32_t* const d_gmeta = d_glen + G;
+    uint8_t* const d_win = reinterpret_cast<uint8_t*>(d_gmeta + G + 16);  // windows of the groups that start inside the first W bytes
+    {
+        std::vector<uint64_t> goff(G);
+        std::vector<uint32_t> glen(G), gmeta(G);
+        for (size_t k = 0; k < G; k++) {
+            goff[k] = out_off + groups[k].v0, glen[k] = groups[k].nout;
+            gmeta[k] = (groups[k].ntok & 0xFFFFFu) | ((wbits - 8) << 20) | (3u << 23);
+        }
+        HIP_OK(hipMemcpyAsync(d_goff, goff.data(), G * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_glen, glen.data(), G * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_gmeta, gmeta.data(), G * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));  // (the vectors go out of scope)
+    }
+    if (dbg_long) fprintf(stderr, "[tamp_amd long decode] %zu groups, %llu tokens, %llu bytes out\n", G, (unsigned long long)tk, (unsigned long long)v);
+    SplitArgs sa;
+    DecompressArgs& a = sa.d;
+    a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len, a.out = d_out, a.out_cap = d_out_cap, a.status = d_status;
+    a.in_consumed = nullptr, a.dict_len = W, a.seed_dicts = ctx->seed_dicts, a.scratch = nullptr, a.only_flagged = nullptr;
+    a.flagged_count = nullptr, a.n_streams = 1, a.lds_row = 0, a.max_wbits = (uint8_t)wbits;
+    sa.lag = nullptr, sa.flagged = nullptr, sa.flagged_count = nullptr, sa.maxcap = kSplitMaxOut, sa.first = 0, sa.count = 1, sa.spw = 64;
+    const uint32_t lds = split_resolve_lds(kSplitMaxOut);
+    auto resolve_kernel = tamp_decode_resolve_kernel<256, 4>;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t early = 0;
+    for (size_t k = 0; k < G; k++) {
+        const Group& gr = groups[k];
+        if (gr.nout == 0) continue;
+        if (gr.v0 < W) {
+            if (early >= 4) { timing_end(st); return TAMP_ERROR; }  // (cannot happen: groups hold >= 11 KiB unless they are the last)
+            uint8_t* const wbuf = d_win + (size_t)early * (1u << 15);
+            early++;
+            hipLaunchKernelGGL(tamp_long_window_kernel, dim3((W + 255) / 256), dim3(256), 0, st, wbuf, out, dict0, (uint32_t)gr.v0, W);
+            a.dict = wbuf;
+        } else {
+            a.dict = out + gr.v0 - W;
+        }
+        a.out_off = d_goff + k, a.out_len = d_glen + k;
+        sa.recs = recs + gr.tok0, sa.meta = d_gmeta + k;
+        sa.tokcap = gr.ntok > 2048 ? gr.ntok : 2048;
+        hipLaunchKernelGGL(resolve_kernel, dim3(1), dim3(256), lds, st, sa);
+    }
+    hipLaunchKernelGGL(tamp_long_finish_kernel, dim3(1), dim3(1), 0, st, d_out_len, d_status, d_consumed, (uint32_t)v, n);
+    timing_end(st);
+    HIP_OK(hipGetLastError());
+    return TAMP_OK;
+}
+
 int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, uint8_t max_wbits, const uint8_t* d_in,
                       const uint64_t* d_in_off, const uint32_t* d_in_len, uint8_t* d_out, const uint64_t* d_out_off,
                       const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
                       size_t n_streams, hipStream_t st) {
     if (n_streams == 0) return TAMP_OK;
+    if (n_streams == 1 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {  // one long v1 stream: the whole device (tamp_decompress_long_kernel.hpp)
+        const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                              d_out_len, d_status, d_consumed, st);
+        if (rc != 1) return rc;
+    }
     DecompressArgs a;
     a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
     a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;

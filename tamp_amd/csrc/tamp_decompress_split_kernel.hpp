@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) tamp_decode_resolve_kernel(SplitArgs sa) 
                 if (nlag && !lit && !from_dict) v = out_of_virtual(v);
                 const uint32_t sp = (lit || from_dict) ? p : v;
                 uint32_t byte = lit ? arg : 0u;
-                if (from_dict) byte = dict[idx];
+                if (from_dict) byte = dict[idx & mask];  // (& mask: groups of one long stream arrive with rotated offsets)
                 src[p] = (uint16_t)sp;
                 outb[p] = (uint8_t)byte;
             }

@@ -16,6 +16,7 @@ if [ "$MODE" = fuzz ]; then
   run decres $((90 * K)) python tools/fuzz_resume_gpu.py
   TAMP_AMD_STATIC_GRID=1 run gpu_static $((60 * K)) python tools/fuzz_gpu.py
   run block $((90 * K)) python tools/fuzz_block_gpu.py
+  run longdec $((90 * K)) python tools/fuzz_long_decode_gpu.py
   for f in $OUT/*.log; do echo "[$(basename $f .log)] $(grep -h 'fuzz\|rc=' $f | tail -2 | tr '\n' ' ')"; done | tee $OUT/summary.txt
 else
   TAG=${TAG:-r4}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
