@@ -737,7 +737,7 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
         DeviceCtx::HostPipe::Grow& gb = ctx->long_scratch[st];
         // worst case records: the shortest token is a literal, 1 + literal bits
         const size_t max_tok = (size_t)(total_bits / (1 + lbits)) + 4096;
-        const size_t b_groups = ((size_t)(max_tok / 256 + N + 64) * 16 + 255) & ~(size_t)255;
+        const size_t b_groups = ((size_t)(max_tok / 256 + N + 64) * (16 + sizeof(LongGroup) + 4) + 255) & ~(size_t)255;
         const size_t bytes = b_tab + max_tok * 4 + b_groups + 4 * (size_t)(1u << 15) + 4096;
         if (gb.need(bytes) != hipSuccess) return 1;
         tab = static_cast<uint8_t*>(gb.p);
@@ -836,6 +836,37 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
         HIP_OK(hipStreamSynchronize(st));  // (the vectors go out of scope)
     }
     if (dbg_long) fprintf(stderr, "[tamp_amd long decode] %zu groups, %llu tokens, %llu bytes out\n", G, (unsigned long long)tk, (unsigned long long)v);
+    const char* chain_env = getenv("TAMP_AMD_LONGDEC_CHAIN");
+    if (!chain_env || atoi(chain_env) != 0) {
+        // all groups in ONE launch: a workgroup per group resolves what lies inside the group at once and waits only for the
+        // bytes of the group in front (tamp_long_resolve_kernel); the table and the flags sit behind the group tables above
+        uint8_t* const ctab = d_win + 4 * (size_t)(1u << 15);
+        LongGroup* const d_groups = reinterpret_cast<LongGroup*>(ctab);
+        uint32_t* const d_flags = reinterpret_cast<uint32_t*>(d_groups + G);
+        uint32_t* const d_err = d_flags + G;
+        {
+            std::vector<LongGroup> tabv(G);
+            for (size_t k = 0; k < G; k++) tabv[k] = LongGroup{groups[k].v0, groups[k].tok0, groups[k].ntok, groups[k].nout, 0};
+            HIP_OK(hipMemcpyAsync(d_groups, tabv.data(), G * sizeof(LongGroup), hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemsetAsync(d_flags, 0, (G + 1) * 4, st));
+            HIP_OK(hipStreamSynchronize(st));
+        }
+        LongResolveArgs ra;
+        ra.recs = recs, ra.groups = d_groups, ra.out = out, ra.dict0 = dict0, ra.flags = d_flags, ra.err = d_err, ra.wbits = wbits;
+        ra.n_groups = (uint32_t)G;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_long_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)long_resolve_lds()));
+        hipLaunchKernelGGL(tamp_long_resolve_kernel, dim3((uint32_t)G), dim3(256), long_resolve_lds(), st, ra);
+        uint32_t err = 1;
+        HIP_OK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (dbg_long) fprintf(stderr, "[tamp_amd long decode] chained resolve: err %u\n", err);
+        if (err) { timing_end(st); return 1; }  // (a wait that gave up: the exact decoder writes the stream again)
+        hipLaunchKernelGGL(tamp_long_finish_kernel, dim3(1), dim3(1), 0, st, d_out_len, d_status, d_consumed, (uint32_t)v, n);
+        timing_end(st);
+        HIP_OK(hipGetLastError());
+        return TAMP_OK;
+    }
     SplitArgs sa;
     DecompressArgs& a = sa.d;
     a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len, a.out = d_out, a.out_cap = d_out_cap, a.status = d_status;

@@ -190,4 +190,212 @@ __global__ void tamp_long_finish_kernel(uint32_t* out_len, int8_t* status, uint3
     if (consumed) consumed[0] = n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Step 3 in ONE launch: a workgroup per group, all groups at once.  What a group needs from the group in front of it are only
+// the bytes its copies take from the window as it stood when the group began; everything inside the group -- the split decoder's
+// token pass, byte pass and pointer jumping (tamp_decode_resolve_kernel, without lags: the v1 format has none) -- does not wait.
+// A byte whose source lies in front of the group becomes EXTERNAL (bit 15 of its pointer, the rotated window index below it),
+// pointer jumping carries that mark to every byte that ends there, and only then the workgroup waits for the flag of the group in
+// front, fetches its external bytes from the output, stores its own bytes and raises its flag: the groups' serial chain is one
+// flag, one gather and one store each instead of a kernel.  Workgroups are dispatched in order (per XCD as well: the oldest
+// unfinished group is always resident), so the wait cannot deadlock; it is bounded all the same, and a group that gives up sets
+// `err` -- the launcher then hands the stream to the exact decoder.
+// ---------------------------------------------------------------------------------------------------------------
+struct LongGroup {
+    unsigned long long v0;  // output position of the group's first byte
+    uint32_t tok0, ntok, nout, pad;
+};
+struct LongResolveArgs {
+    const uint32_t* recs;
+    const LongGroup* groups;
+    uint8_t* out;            // the stream's output
+    const uint8_t* dict0;    // the window of a fresh decoder (custom dictionary or the seeded default)
+    uint32_t* flags;         // one per group, zeroed: 1 = its bytes are in `out`
+    uint32_t* err;
+    uint32_t wbits;
+    uint32_t n_groups;
+};
+constexpr uint32_t kLongExt = 0x8000u;
+__host__ __device__ constexpr uint32_t long_resolve_lds() { return (kSplitMaxOut + 16) + 2 * kSplitMaxOut + 128; }
+
+__global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t nt = 256, BPT = 4;
+    const uint32_t g = blockIdx.x;
+    const LongGroup gr = ra.groups[g];
+    const uint32_t n_out = gr.nout, ntok = gr.ntok;
+    const uint32_t W = 1u << ra.wbits, mask = W - 1;
+    const uint32_t* const rec = ra.recs + gr.tok0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t capa = kSplitMaxOut;
+    uint8_t* const outb = smem;
+    uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);
+    typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
+    LdsCtl* const ctl = (LdsCtl*)(smem + capa + 16 + 2 * capa);
+    if (n_out) {
+        for (uint32_t i = tid; i < capa / 2; i += nt) reinterpret_cast<uint32_t*>(src)[i] = 0;
+        __syncthreads();
+        {   // token pass: every token leaves its number + 1 at the output position where it starts
+            const uint32_t K = (ntok + nt - 1) / nt;
+            const uint32_t j0 = min(tid * K, ntok), j1 = min(j0 + K, ntok);
+            uint32_t sum = 0;
+            for (uint32_t j = j0; j < j1; j++) sum += (rec[j] >> 2) & 0xFFu;
+            const uint32_t incl = wave_scan_add(sum);
+            if (lane == 63) ctl[wave] = incl;
+            __syncthreads();
+            uint32_t O = incl - sum;
+            for (uint32_t w2 = 0; w2 < wave; w2++) O += ctl[w2];
+            for (uint32_t j = j0; j < j1; j++) {
+                const uint32_t olen = (rec[j] >> 2) & 0xFFu;
+                if (olen) src[O] = (uint16_t)(j + 1);
+                O += olen;
+            }
+        }
+        __syncthreads();
+        // byte pass: a final byte (literal), a pointer to an earlier byte of the group, or an external mark
+        for (uint32_t r0 = 0, carry = 0; r0 < n_out; r0 += BPT * nt) {
+            const uint32_t p0 = r0 + BPT * tid;
+            uint2 lo = make_uint2(0, 0);
+            if (p0 < capa) lo = *reinterpret_cast<const uint2*>(src + p0);
+            const uint32_t h[2] = {lo.x, lo.y};
+            uint32_t last = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < BPT; i++)
+                if ((h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) last = p0 + i + 1;
+            const uint32_t inc = wave_scan_max(last);
+            if (lane == 63) ctl[8 + wave] = inc;
+            __syncthreads();
+            uint32_t head = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);
+            for (uint32_t w2 = 0; w2 < wave; w2++) head = max(head, (uint32_t)ctl[8 + w2]);
+            const uint32_t carry_in = carry;
+            head = max(head, carry);
+            uint32_t wgmax = carry;
+            for (uint32_t w2 = 0; w2 < 4; w2++) wgmax = max(wgmax, (uint32_t)ctl[8 + w2]);
+            carry = wgmax;
+            uint32_t jcur = 0;
+            if (head) jcur = (head == carry_in && r0) ? (uint32_t)ctl[12] : (uint32_t)src[head - 1] - 1u;
+            uint32_t hpos = head ? head - 1 : 0u;
+            __syncthreads();  // every mark has been read: `src` may be overwritten with pointers now
+            if (p0 < n_out) {
+                uint32_t kind = 0, arg = 0, Vj = 0;
+                const uint32_t pend = min(p0 + BPT, n_out);
+                if (head) {
+                    const uint32_t r = rec[jcur];
+                    kind = r & 3u, arg = r >> 10, Vj = hpos;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < BPT; i++) {
+                    const uint32_t p = p0 + i;
+                    if (p >= pend) break;
+                    const uint32_t m = (h[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                    if (m) {
+                        jcur = m - 1, hpos = p;
+                        const uint32_t r = rec[jcur];
+                        kind = r & 3u, arg = r >> 10, Vj = hpos;
+                    }
+                    const bool lit = kind == kRecLit;
+                    const uint32_t idx = (arg + (p - hpos)) & mask;  // (rotated) ring index read
+                    const uint32_t back = (Vj - 1 - idx) & mask;      // 0 = newest ... W-1 = oldest
+                    const bool ext = !lit && back >= Vj;              // not written by this group: the window in front of it
+                    const uint32_t v = Vj - 1 - back;
+                    src[p] = (uint16_t)(lit ? p : (ext ? (kLongExt | idx) : v));
+                    outb[p] = (uint8_t)(lit ? arg : 0u);
+                }
+                if (tid == nt - 1) ctl[12] = jcur;
+            }
+            __syncthreads();
+        }
+        // pointer jumping; final = points at itself, external = bit 15 (both end a chain)
+        uint32_t um[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            if (q * 16 * nt < n_out) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t p = q * 16 * nt + i * nt + tid;
+                    if (p < n_out) {
+                        const uint32_t sp = src[p];
+                        um[q] |= ((sp != p && !(sp & kLongExt)) ? 1u : 0u) << i;
+                    }
+                }
+            }
+        }
+        for (uint32_t round = 0; round < 20; round++) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t pq = q * 16 * nt + tid;
+                for (uint32_t m = um[q]; m;) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t p = pq + i * nt;
+                    const uint32_t s1 = src[p];          // (a position: p is unresolved)
+                    const uint32_t s2 = src[s1];
+                    asm volatile("" ::: "memory");
+                    if (s2 & kLongExt) {                 // s1 is external: so is p
+                        src[p] = (uint16_t)s2;
+                        um[q] &= ~(1u << i);
+                    } else if (s2 == s1) {               // s1 is final
+                        outb[p] = outb[s1];
+                        asm volatile("" ::: "memory");
+                        src[p] = (uint16_t)p;
+                        um[q] &= ~(1u << i);
+                    } else {
+                        src[p] = (uint16_t)s2;           // one hop closer
+                    }
+                }
+            }
+            if (!__syncthreads_or((int)(um[0] | um[1] | um[2] | um[3]))) break;
+        }
+    }
+    // ---- the group in front: wait for its bytes ----
+    bool failed = false;
+    if (g > 0) {
+        if (tid == 0) {
+            uint32_t spins = 0;
+            // (relaxed: an acquire at agent scope invalidates the XCD's whole L2 -- 1,891 of them per 30 MB slowed every
+            // workgroup's record reads, 229 ms against 92 for launches in a row; the bytes behind the flag are fetched with
+            // agent-scope atomic loads below, which do not look at stale lines either)
+            while (__hip_atomic_load(ra.flags + (g - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (__hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > (1u << 24)) {
+                    __hip_atomic_store(ra.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            ctl[13] = __hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        failed = ctl[13] != 0;
+    }
+    if (!failed && n_out) {
+        const unsigned long long v0 = gr.v0;
+        const uint32_t wp0 = (uint32_t)(v0 & mask);
+        uint8_t* const out = ra.out + v0;
+        for (uint32_t p = tid; p < n_out; p += nt) {
+            const uint32_t sp = src[p];
+            if (sp & kLongExt) {
+                const uint32_t j = sp & 0x7FFFu;  // j-th oldest byte of the window in front of the group
+                uint32_t b;
+                if (v0 >= W) {
+                    b = __hip_atomic_load(ra.out + (v0 - W + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const uint32_t r = (j + wp0) & mask;
+                    b = r < (uint32_t)v0 ? __hip_atomic_load(ra.out + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ra.dict0[r];
+                }
+                outb[p] = (uint8_t)b;
+            }
+        }
+        __syncthreads();
+        const uint32_t head = min((uint32_t)((4 - (reinterpret_cast<uintptr_t>(out) & 3)) & 3), n_out);
+        if (tid < head) out[tid] = outb[tid];
+        const uint32_t ndw = (n_out - head) >> 2;
+        uint32_t* const out32 = reinterpret_cast<uint32_t*>(out + head);
+        for (uint32_t i = tid; i < ndw; i += nt) out32[i] = lds_u32_unaligned(outb, head + 4 * i);
+        for (uint32_t i = head + 4 * ndw + tid; i < n_out; i += nt) out[i] = outb[i];
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0 && !failed) __hip_atomic_store(ra.flags + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace tamp_amd

@@ -77,6 +77,10 @@ def test_one_long_v1_stream_decodes_like_the_reference(ta, checker, name, conf, 
     assert bytes(ta.decompress(blob)) == data
     st, out = _same_as_checker(ta, checker, blob, n + 100)
     assert st == 2 and out == data
+    # groups through RESOLVE one launch after the other: the same bytes
+    monkeypatch.setenv("TAMP_AMD_LONGDEC_CHAIN", "0")
+    r = ta.decompress_batch([blob], out_cap=n + 100)
+    assert int(r.status[0]) == 2 and bytes(r.stream(0)) == data
     # the exact decoders give the same answer (the path the launcher falls back to)
     monkeypatch.setenv("TAMP_AMD_LONGDEC", "0")
     r = ta.decompress_batch([blob], out_cap=n + 100)
@@ -127,8 +131,8 @@ def test_what_the_long_stream_decoder_declines_goes_to_the_exact_decoders(ta, ch
 
 
 def test_long_stream_decode_rate(ta):
-    """32 MB of prose, v1: the stream came back at 7.3 MB/s through one wavefront; the bar here is 100 MB/s end to end
-    through the host-memory call (measured: ~250)."""
+    """32 MB of prose, v1: the stream came back at 7.3 MB/s through one wavefront; the bar here is 150 MB/s end to end
+    through the host-memory call (measured: ~500; groups resolved one launch after the other: ~250)."""
     import time
 
     data = _corpus("prose", 32_000_000)
@@ -138,4 +142,4 @@ def test_long_stream_decode_rate(ta):
     out = ta.decompress(blob)
     dt = time.time() - t0
     assert bytes(out) == data
-    assert len(data) / dt > 100e6, dt
+    assert len(data) / dt > 150e6, dt
