@@ -1692,6 +1692,9 @@ long long tamp_amd_trim(int device) {
         std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
         for (auto& kv : ctx->lpt_scratch)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
+        std::lock_guard<std::mutex> long_lock(ctx->long_mu);  // (the long-stream decoder's chunk tables and records)
+        for (auto& kv : ctx->long_scratch)
+            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
     }
     {   // the host-memory pipeline: pinned staging of non-tiling output slabs (it grows with the largest extent ever staged,
         // possibly gigabytes of pinned RAM) and the device-side chunk buffers; both grow again on demand
