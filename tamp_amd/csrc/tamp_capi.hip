@@ -905,11 +905,6 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
                       const uint32_t* d_out_cap, uint32_t* d_out_len, int8_t* d_status, uint32_t* d_consumed,
                       size_t n_streams, hipStream_t st) {
     if (n_streams == 0) return TAMP_OK;
-    if (n_streams == 1 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {  // one long v1 stream: the whole device (tamp_decompress_long_kernel.hpp)
-        const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                              d_out_len, d_status, d_consumed, st);
-        if (rc != 1) return rc;
-    }
     DecompressArgs a;
     a.in = d_in, a.in_off = d_in_off, a.in_len = d_in_len;
     a.out = d_out, a.out_off = d_out_off, a.out_cap = d_out_cap, a.out_len = d_out_len, a.status = d_status;
@@ -926,6 +921,11 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         call_slab = &ctx->slabs[st];  // (map nodes do not move)
     }
     std::lock_guard<std::mutex> call_lock(call_slab->launch_mu);
+    if (n_streams == 1 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {  // one long v1 stream: the whole device (tamp_decompress_long_kernel.hpp)
+        const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                              d_out_len, d_status, d_consumed, st);
+        if (rc != 1) return rc;
+    }
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
     uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)
     uint64_t window_bytes = 0;          // sum of the streams' window sizes (0 = unknown)
