@@ -407,9 +407,18 @@ def also_one_long_stream(torch, np, n=100_000_000):
     want = impl.compress_batch(flat[:k], np.zeros(1, np.uint64), np.array([k], np.uint32), window=10, literal=8, extended=False).stream(0)
     got = tamp_amd.compress_batch(d[:k], off, torch.tensor([k], dtype=torch.int32, device=dev), window=10, literal=8,
                                   extended=False, max_in_len=k).stream(0)
+    # ... and back: ONE stream decoded by the whole device (tamp_decompress_long_kernel.hpp), stream and output in HBM
+    clen = int(r.out_len[0])
+    dms, back = [], None
+    for _ in range(3):
+        back = tamp_amd.decompress_batch(r.out[:clen], off, torch.tensor([clen], dtype=torch.int32, device=dev), out_cap=n + 64, timing=True)
+        dms.append(float(back.kernel_ms))
+    same = int(back.status[0]) == 2 and int(back.out_len[0]) == n and bool(torch.equal(back.out[:n], d))
     return {"bytes": n, "format": "v1 (extended=0), window=10 literal=8", "kernel_ms": round(min(ms[1:]), 3),
             "input_GBps": round(n / (min(ms[1:]) * 1e-3) / 1e9, 2), "status": int(r.status[0]),
             "ratio": round(int(r.out_len[0]) / n, 4), "parity_4MiB_stream": ("bit-exact" if got == want else "MISMATCH") + f" vs {kind}",
+            "decode_kernel_ms": round(min(dms[1:]), 2), "decode_output_GBps": round(n / (min(dms[1:]) * 1e-3) / 1e9, 2),
+            "decode_round_trip": "equal" if same else "MISMATCH",
             "note": "extended-format streams keep one workgroup per stream: their lags make the window depend on the parse"}
 
 
