@@ -792,6 +792,9 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     HIP_OK(hipStreamSynchronize(st));
     if (fl[1]) { timing_end(st); return 1; }  // an out-of-bounds offset: the exact decoder reports where
     // groups of whole chunks: at most kSplitMaxOut output bytes and 2^20 - 1 records each
+    const char* chain_env = getenv("TAMP_AMD_LONGDEC_CHAIN");
+    const bool chain = !chain_env || atoi(chain_env) != 0;
+    const uint32_t group_out = chain ? kLongGroupOut : kSplitMaxOut;
     struct Group { uint64_t v0; uint32_t tok0, ntok, nout; };
     std::vector<Group> groups;
     std::vector<uint32_t> tokbase(N), rot(N);
@@ -799,7 +802,7 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     {
         Group gcur{0, 0, 0, 0};
         for (uint32_t i = 0; i < N; i++) {
-            if (gcur.nout + outb[i] > kSplitMaxOut || gcur.ntok + ntok[i] > 0xFFFFFu) {
+            if (gcur.nout + outb[i] > group_out || gcur.ntok + ntok[i] > 0xFFFFFu) {
                 groups.push_back(gcur);
                 gcur = Group{v, (uint32_t)tk, 0, 0};
             }
@@ -836,8 +839,7 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
         HIP_OK(hipStreamSynchronize(st));  // (the vectors go out of scope)
     }
     if (dbg_long) fprintf(stderr, "[tamp_amd long decode] %zu groups, %llu tokens, %llu bytes out\n", G, (unsigned long long)tk, (unsigned long long)v);
-    const char* chain_env = getenv("TAMP_AMD_LONGDEC_CHAIN");
-    if (!chain_env || atoi(chain_env) != 0) {
+    if (chain) {
         // all groups in ONE launch: a workgroup per group resolves what lies inside the group at once and waits only for the
         // bytes of the group in front (tamp_long_resolve_kernel); the table and the flags sit behind the group tables above
         uint8_t* const ctab = d_win + 4 * (size_t)(1u << 15);

@@ -216,7 +216,10 @@ struct LongResolveArgs {
     uint32_t n_groups;
 };
 constexpr uint32_t kLongExt = 0x8000u;
-__host__ __device__ constexpr uint32_t long_resolve_lds() { return (kSplitMaxOut + 16) + 2 * kSplitMaxOut + 128; }
+// output bytes per group of the one-launch resolve: twice RESOLVE's -- the groups' chain is serial, fewer and larger links are
+// faster (100 MB: 92 -> see DESIGN.md 4), and 96 KB of LDS still leaves a workgroup per CU waiting on every CU
+constexpr uint32_t kLongGroupOut = 32768;
+__host__ __device__ constexpr uint32_t long_resolve_lds() { return (kLongGroupOut + 16) + 2 * kLongGroupOut + 128; }
 
 __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs ra) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
     const uint32_t W = 1u << ra.wbits, mask = W - 1;
     const uint32_t* const rec = ra.recs + gr.tok0;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t capa = kSplitMaxOut;
+    const uint32_t capa = kLongGroupOut;
     uint8_t* const outb = smem;
     uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);
     typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
@@ -306,9 +309,10 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
             __syncthreads();
         }
         // pointer jumping; final = points at itself, external = bit 15 (both end a chain)
-        uint32_t um[4] = {0, 0, 0, 0};
+        constexpr uint32_t NQ = kLongGroupOut / (16 * nt);  // masks of 16 positions per thread
+        uint32_t um[NQ] = {};
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
+        for (uint32_t q = 0; q < NQ; q++) {
             if (q * 16 * nt < n_out) {
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) {
@@ -322,7 +326,7 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
         }
         for (uint32_t round = 0; round < 20; round++) {
 #pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
+            for (uint32_t q = 0; q < NQ; q++) {
                 const uint32_t pq = q * 16 * nt + tid;
                 for (uint32_t m = um[q]; m;) {
                     const uint32_t i = (uint32_t)__builtin_ctz(m);
@@ -344,7 +348,25 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
                     }
                 }
             }
-            if (!__syncthreads_or((int)(um[0] | um[1] | um[2] | um[3]))) break;
+            uint32_t any = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < NQ; q++) any |= um[q];
+            if (!__syncthreads_or((int)any)) break;
+        }
+    }
+    // which of this thread's bytes are external: noted BEFORE the wait (behind it, a scan of all positions with a load inside
+    // was 13 us of the 26 a 32 KiB group spent in the serial part)
+    constexpr uint32_t NE = kLongGroupOut / (32 * nt);
+    uint32_t em[NE] = {};
+    if (n_out) {
+#pragma unroll
+        for (uint32_t w = 0; w < NE; w++) {
+            if (w * 32 * nt < n_out) {
+                for (uint32_t i = 0; i < 32; i++) {
+                    const uint32_t p = (w * 32 + i) * nt + tid;
+                    if (p < n_out && (src[p] & kLongExt)) em[w] |= 1u << i;
+                }
+            }
         }
     }
     // ---- the group in front: wait for its bytes ----
@@ -371,10 +393,13 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
         const unsigned long long v0 = gr.v0;
         const uint32_t wp0 = (uint32_t)(v0 & mask);
         uint8_t* const out = ra.out + v0;
-        for (uint32_t p = tid; p < n_out; p += nt) {
-            const uint32_t sp = src[p];
-            if (sp & kLongExt) {
-                const uint32_t j = sp & 0x7FFFu;  // j-th oldest byte of the window in front of the group
+#pragma unroll
+        for (uint32_t w = 0; w < NE; w++) {
+            for (uint32_t m = em[w]; m;) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t p = (w * 32 + i) * nt + tid;
+                const uint32_t j = (uint32_t)src[p] & 0x7FFFu;  // j-th oldest byte of the window in front of the group
                 uint32_t b;
                 if (v0 >= W) {
                     b = __hip_atomic_load(ra.out + (v0 - W + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
