@@ -442,3 +442,80 @@ def test_bench_flags_of_round_5_exist_and_the_probe_is_opt_in():
         assert flag in out.stdout, flag
     src = open(os.path.join(root, "bench.py")).read()
     assert "wl.probe_corpus(env={}, fetch=(args.fetch_corpus and rank == 0))" in src  # (never without --probe-corpus, never fetching by default)
+
+
+def test_long_stream_chunk_starts_settle_on_the_token_boundaries(oracle):
+    """The idea behind tamp_decompress_long_kernel.hpp, restated on the CPU: cut a v1 stream's bits into chunks, parse every chunk
+    from a GUESSED start, hand each chunk's exit to the next chunk as its start, repeat -- the fixed point is the sequential
+    parse's own boundaries (chunk 0 starts behind the header), text gets there in two or three rounds, and a run of one token
+    (a periodic bit stream never re-synchronises) a chunk per round.  Token grammar: decompressor.c:431-575 (v1)."""
+    import tamp_amd
+    from tamp_amd import workloads as wl
+
+    codes_lo, codes_hi, nbits = 0x2B2624140B080300, 0x00AB27AA9594544B, 0x979998877765532
+    table = {"0": 0}
+    for sy in range(1, 15):
+        l = ((nbits >> (4 * sy)) & 15) - 1
+        code = ((codes_lo >> (8 * sy)) if sy < 8 else (codes_hi >> (8 * (sy - 8)))) & 0xFF
+        table["1" + format(code & ((1 << (l - 1)) - 1), f"0{l - 1}b") if l > 1 else "1"] = sy
+    assert len(table) == 15 and abs(sum(2.0 ** -len(k) for k in table) - 1.0) < 1e-12  # a complete prefix code
+
+    def token(bits, t, wbits, lbits):  # -> bits the token at t takes (0: the stream ends), bytes it yields
+        n = len(bits)
+        if t >= n:
+            return 0, 0
+        if bits[t] == "1":
+            return (1 + lbits, 1) if t + 1 + lbits <= n else (0, 0)
+        k = 1
+        while True:
+            if t + 1 + k > n:
+                return 0, 0
+            sym = table.get(bits[t + 1 : t + 1 + k])
+            if sym is not None:
+                break
+            k += 1
+        if sym == 14:  # FLUSH: to the byte boundary
+            u = 1 + k
+            return u + (-(t + u)) % 8, 0
+        if t + 1 + k + wbits > n:
+            return 0, 0
+        return 1 + k + wbits, sym + minp
+
+    C = 512
+    for name, data, window in (("text", bytes(wl.synth_text(1, 30_000)[0]), 10), ("runs", bytes(wl.lcg_runs(1, 20_000)[0]), 8),
+                               ("zeros", bytes(40_000), 10), ("period", (b"abcdefghijklmnopqrstuvw" * 2000)[:40_000], 12)):
+        st, blob = oracle.stream_script([("write", data[: len(data) // 2]), ("flush", True), ("write", data[len(data) // 2 :]), ("close",)],
+                                        window=window, literal=8, extended=False)
+        assert st == 0
+        minp = tamp_amd.compute_min_pattern_size(window, 8)  # (host helper: a pure function, tamp/__init__.py:54-70)
+        bits = "".join(format(b, "08b") for b in blob)
+        # the sequential parse: boundaries and output size
+        bounds, t, total = set(), 8, 0
+        while True:
+            bounds.add(t)
+            k, nb = token(bits, t, window, 8)
+            if not k:
+                break
+            t += k
+            total += nb
+        assert total == len(data), name
+        N = (len(bits) + C - 1) // C
+        g = [i * C for i in range(N + 1)]
+        g[0] = 8
+        rounds = 0
+        while True:
+            nxt = list(g)
+            for i in range(N):
+                t = g[i]
+                while t is not None and t < (i + 1) * C:
+                    k, _ = token(bits, t, window, 8)
+                    t = t + k if k else None
+                nxt[i + 1] = t
+            rounds += 1
+            if nxt == g:
+                break
+            g = nxt
+            assert rounds <= N + 2, name
+        assert all(x is None or x in bounds for x in g[:-1]), name  # every settled start is a true token boundary
+        if name in ("text", "runs"):
+            assert rounds <= 4, (name, rounds)
