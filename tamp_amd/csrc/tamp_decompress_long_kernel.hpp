@@ -4,17 +4,20 @@
 // Replaces, for one stream, tamp_decompressor_decompress (tamp/_c_src/tamp/decompressor.c:371-578) where its token loop is
 // position-independent: the v1 format without a dictionary reset -- a literal is 1 + literal bits, a match is the flag, a
 // prefix code (decompressor.c:52-104) and window bits, FLUSH pads to the byte boundary (:501-514), and none of it depends
-// on the window.  A wavefront per stream decodes such a stream at ~700 cycles per token (7 MB/s); here
+// on the window.  A wavefront per stream decodes such a stream at ~700 cycles per token (7 MB/s; this path: 2.3 GB/s); here
 //
 //   1. the compressed bits are cut into chunks of kLongChunkBits and a lane per chunk parses from a GUESSED start; the
-//      position where it leaves its chunk is the next chunk's start for the next round (tamp_long_sync_kernel).  Chunk 0
-//      starts behind the header, so after round k the first k chunks are certainly right, and a prefix code re-synchronises
-//      within a few tokens: the guesses stop changing after two to four rounds.  Unchanged guesses everywhere = all right;
-//   2. a lane per chunk counts its tokens and bytes, the host cuts the chunks into groups of at most kSplitMaxOut output
+//      position where it leaves its chunk is the next chunk's start for the next round (tamp_long_sync_kernel; the 64 chunks
+//      of a workgroup settle among themselves first).  Chunk 0 starts behind the header, so after round k the first k chunk
+//      rows are certainly right, and a prefix code re-synchronises within a few tokens: text settles in two rounds of the
+//      host's loop.  Unchanged guesses everywhere = all right (tests/test_host_logic.py restates this on the CPU);
+//   2. a lane per chunk counts its tokens and bytes, the host cuts the chunks into groups of at most kLongGroupOut output
 //      bytes, a lane per chunk writes the split decoder's 32-bit records (tamp_long_parse_kernel);
-//   3. the groups go through the split decoder's RESOLVE (tamp_decompress_split_kernel.hpp) IN ORDER, each with the W output
-//      bytes in front of it as its "dictionary": a group is a stream whose window is rotated so that its write cursor starts
-//      at 0 (window offsets are rotated with it when the records are written).
+//   3. ONE launch resolves all groups, a workgroup each (tamp_long_resolve_kernel below): everything inside a group at once,
+//      the bytes it takes from the window in front of it when the group in front has stored its own.  A group is a stream
+//      whose window is rotated so that its write cursor starts at 0 (window offsets are rotated with it when the records are
+//      written).  (TAMP_AMD_LONGDEC_CHAIN=0: groups of kSplitMaxOut bytes through the split decoder's RESOLVE, one launch
+//      after the other, each with the W output bytes in front of it as its "dictionary".)
 //
 // Anything else -- extended format, dictionary reset, an out-of-bounds offset, an output buffer that is too small, a sync
 // that does not settle -- is left to the exact decoders: the launcher falls back before anything has been written.
