@@ -923,10 +923,18 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
         call_slab = &ctx->slabs[st];  // (map nodes do not move)
     }
     std::lock_guard<std::mutex> call_lock(call_slab->launch_mu);
-    if (n_streams == 1 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {  // one long v1 stream: the whole device (tamp_decompress_long_kernel.hpp)
-        const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                              d_out_len, d_status, d_consumed, st);
-        if (rc != 1) return rc;
+    if (n_streams <= 16 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {
+        // one long v1 stream -- or a handful, one after the other: the whole device each (tamp_decompress_long_kernel.hpp).  A stream
+        // that is not one (too short, extended, ...) sends the whole call to the decoders below, which write every stream again.
+        size_t done = 0;
+        for (; done < n_streams; done++) {
+            const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off + done, d_in_len + done, d_out,
+                                                  d_out_off + done, d_out_cap + done, d_out_len + done, d_status + done,
+                                                  d_consumed ? d_consumed + done : nullptr, st);
+            if (rc == 1) break;
+            if (rc != TAMP_OK) return rc;
+        }
+        if (done == n_streams) return TAMP_OK;
     }
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
     uint32_t longest_in = 0xFFFFFFFFu;  // longest compressed stream of the batch (unknown without the pre-pass)

@@ -143,3 +143,21 @@ def test_long_stream_decode_rate(ta):
     dt = time.time() - t0
     assert bytes(out) == data
     assert len(data) / dt > 150e6, dt
+
+
+def test_a_handful_of_long_streams_in_one_call(ta, checker):
+    """Up to sixteen long v1 streams in one decode call take the long-stream decoder one after the other; a batch with a short or an
+    extended-format stream among them goes to the exact decoders whole.  Same bytes, statuses and consumed counts either way."""
+    datas = [_corpus("prose", 700_000), _corpus("python", 900_000), _corpus("markup", 650_000)]
+    blobs = [ta.compress(d, extended=False) for d in datas]
+    r = ta.decompress_batch(blobs, out_cap=1_000_000)
+    for i, (b, d) in enumerate(zip(blobs, datas)):
+        st, out, used = checker.decompress(b, cap=1_000_000)
+        assert (int(r.status[i]), bytes(r.stream(i))) == (st, out) and out == d
+        if r.in_consumed is not None:
+            assert int(r.in_consumed[i]) == used
+    mixed = blobs + [ta.compress(datas[0][:5000], extended=False), ta.compress(datas[1], extended=True)]
+    r = ta.decompress_batch(mixed, out_cap=1_000_000)
+    for i, b in enumerate(mixed):
+        st, out, used = checker.decompress(b, cap=1_000_000)
+        assert (int(r.status[i]), bytes(r.stream(i))) == (st, out)
