@@ -379,7 +379,8 @@ def decompress(data: bytes, *args, **kwargs) -> bytearray:
         # would take the one-wavefront decoder to find that out)
         r = decompress_batch([blob], out_cap=12 * len(blob) + 64, dictionary=kwargs.get("dictionary"))
         if int(r.status[0]) == _lib.INPUT_EXHAUSTED:
-            return bytearray(r.stream(0))
+            o, n = int(r.out_off[0]), int(r.out_len[0])
+            return bytearray(memoryview(r.out)[o : o + n])  # (one copy of the bytes, not two)
     with BytesIO(blob) as f:
         d = Decompressor(f, *args, **kwargs)
         return d.read()
