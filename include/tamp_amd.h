@@ -150,6 +150,13 @@ int tamp_amd_compress_plan(uint8_t window_bits, uint32_t max_in_len, int lazy_ma
  *                                               stream.  With device memory the call is asynchronous on `stream`;
  *                                               with host memory the call is synchronous and runs on the
  *                                               library's own streams (`stream` is not used).
+ *                                               ONE EXCEPTION to "asynchronous": a device-memory call of at most 64
+ *                                               streams with max_in_len >= 256 KiB in the v1 format (extended = 0,
+ *                                               literal = 8, default parse) reads the streams' table rows back and
+ *                                               WAITS for `stream` once before it launches (block mode: one long
+ *                                               stream over all workgroups) -- such a call cannot be captured in a
+ *                                               hipGraph; the environment variable TAMP_AMD_BLOCK_MIN=0 turns block
+ *                                               mode off and restores the asynchronous batch kernel for them.
  * Returns TAMP_OK when the batch was launched (per-stream results are in status[]), or a negative
  * library-level code.
  */

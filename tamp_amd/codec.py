@@ -213,11 +213,15 @@ class TextCompressor(Compressor):
 #: one-shot ``compress()`` calls of at least this many bytes in the v1 format go to the batch call as ONE stream, which
 #: spreads its blocks over all workgroups (tamp_compress_kernel<.., BLOCKM>; csrc/tamp_capi.hip launch_compress_blocks)
 ONE_SHOT_BLOCK_MIN = 256 << 10
+# The batch tables hold 32-bit lengths: a one-shot call beyond that stays with the streaming object, which cuts the data into
+# pieces.  Decoding: 2^29 - 1 compressed bytes per call (kMaxDecodeIn, tamp_common.hpp) and a capacity that fits 32 bits.
+ONE_SHOT_MAX_IN = 0xFFFFFFFF
+ONE_SHOT_MAX_DECODE_IN = (1 << 29) - 1
 
 
 def compress(data: Union[bytes, str], *args, **kwargs) -> bytes:
     """``tamp.compress`` (tamp/_c_compressor.pyx:189-199)."""
-    if (not args and isinstance(data, (bytes, bytearray, memoryview)) and len(data) >= ONE_SHOT_BLOCK_MIN
+    if (not args and isinstance(data, (bytes, bytearray, memoryview)) and ONE_SHOT_BLOCK_MIN <= len(data) <= ONE_SHOT_MAX_IN
             and kwargs.get("extended", True) is False and kwargs.get("literal", 8) == 8
             and not kwargs.get("lazy_matching") and not kwargs.get("dictionary_reset") and not kwargs.get("append")
             and set(kwargs) <= {"window", "literal", "dictionary", "extended", "lazy_matching", "dictionary_reset", "append", "device"}):
@@ -375,12 +379,19 @@ def decompress(data: bytes, *args, **kwargs) -> bytearray:
     blob = bytes(data)
     if len(blob) >= ONE_SHOT_BLOCK_MIN and not args and set(kwargs) <= {"dictionary"} and (blob[0] & 3) == 0:
         from .batch import decompress_batch
-        # (room for the worst case at once -- a v1 match token of 2 + 8 bits yields up to 15 bytes: a call that runs out of room
-        # would take the one-wavefront decoder to find that out)
-        r = decompress_batch([blob], out_cap=12 * len(blob) + 64, dictionary=kwargs.get("dictionary"))
-        if int(r.status[0]) == _lib.INPUT_EXHAUSTED:
-            o, n = int(r.out_off[0]), int(r.out_len[0])
-            return bytearray(memoryview(r.out)[o : o + n])  # (one copy of the bytes, not two)
+        # Room for the worst case at once (a call that runs out of room would take the one-wavefront decoder to find that
+        # out): the densest v1 token is a 15-byte match in 7 + 8 bits (window 2^8, compressor.c:33-36) -- 8 bytes per byte.
+        # A blob whose worst case does not fit the 32-bit capacity, or that the device cannot hold 9 x of, takes the
+        # streaming object below, as every input did before this shortcut existed.
+        cap = 8 * len(blob) + 64
+        if len(blob) <= ONE_SHOT_MAX_DECODE_IN and cap <= 0xFFFFFFFF:
+            try:
+                r = decompress_batch([blob], out_cap=cap, dictionary=kwargs.get("dictionary"))
+            except (MemoryError, OverflowError, _lib.NativeLibraryError):  # (the object below reports what is really wrong)
+                r = None
+            if r is not None and int(r.status[0]) == _lib.INPUT_EXHAUSTED:
+                o, n = int(r.out_off[0]), int(r.out_len[0])
+                return bytearray(memoryview(r.out)[o : o + n])  # (one copy of the bytes, not two)
     with BytesIO(blob) as f:
         d = Decompressor(f, *args, **kwargs)
         return d.read()

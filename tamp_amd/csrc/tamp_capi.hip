@@ -103,6 +103,15 @@ struct DeviceCtx {
     std::map<hipStream_t, HostPipe::Grow> long_scratch;  // one long stream decoded by the whole device: chunk tables, records
     std::mutex lpt_mu;
     std::map<hipStream_t, HostPipe::Grow> lpt_scratch;
+    // one enqueue at a time per HIP stream for the compress launches that keep per-stream scratch (the expensive-first
+    // tables): held from the scratch look-up to the last kernel of the call, so that a second host thread on the same stream
+    // can neither interleave its helper kernels with this call's nor grow (free) the buffer this call is about to launch
+    // with; tamp_amd_trim takes it before it frees.  (Looked up under lpt_mu; map nodes do not move.)
+    std::map<hipStream_t, std::mutex> enqueue_mu;
+    std::mutex& enqueue_lock(hipStream_t st) {
+        std::lock_guard<std::mutex> lock(lpt_mu);
+        return enqueue_mu[st];
+    }
 };
 
 DeviceCtx g_ctx[kMaxDevices];
@@ -185,7 +194,9 @@ struct DevBuf {  // RAII device allocation for host-memory calls
     T* as() { return static_cast<T*>(p); }
 };
 
+thread_local bool t_timing_outer = false;  // a caller's event pair spans several inner launches (up to sixteen long streams)
 void timing_begin(hipStream_t st) {
+    if (t_timing_outer) return;
     t_ev_valid = false;
     if (!t_timing) return;
     if (!t_ev0) {
@@ -592,6 +603,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
             return TAMP_AMD_BAD_ARGUMENT;
         }
         // (every argument check lies in front of the event pair: a refused call leaves no half-recorded timing)
+        std::lock_guard<std::mutex> enqueue(ctx->enqueue_lock(st));  // (per HIP stream; see DeviceCtx::enqueue_mu)
         timing_begin(st);
         // expensive streams first, for batches of more than one and at most ~18 rounds of the grid (beyond, the tail is short
         // next to the batch; TAMP_AMD_LPT=0 / =1 force it off / on)
@@ -710,7 +722,9 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     uint32_t n = 0, cap = 0;
     HIP_OK(hipMemcpyAsync(&n, d_in_len, 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (n < min_len || n > kMaxDecodeIn) return 1;
+    // (the chunk kernels count bits in 32-bit registers: (i + 1) * kLongChunkBits wraps for the last chunk of the top 512 bytes of
+    // the accepted range -- those streams stay with the exact decoder)
+    if (n < min_len || n > kMaxDecodeIn - 512) return 1;
     HIP_OK(hipMemcpyAsync(&in_off, d_in_off, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(&out_off, d_out_off, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(&cap, d_out_cap, 4, hipMemcpyDeviceToHost, st));
@@ -926,14 +940,19 @@ int launch_decompress(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_len, ui
     if (n_streams <= 16 && !(max_wbits & TAMP_AMD_WINDOW_BITS_EXACT)) {
         // one long v1 stream -- or a handful, one after the other: the whole device each (tamp_decompress_long_kernel.hpp).  A stream
         // that is not one (too short, extended, ...) sends the whole call to the decoders below, which write every stream again.
+        // (one event pair around all of them: kernel_ms of a call with several long streams is the sum, not the last stream's)
         size_t done = 0;
+        timing_begin(st);
+        t_timing_outer = true;
+        int rc = TAMP_OK;
         for (; done < n_streams; done++) {
-            const int rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off + done, d_in_len + done, d_out,
-                                                  d_out_off + done, d_out_cap + done, d_out_len + done, d_status + done,
-                                                  d_consumed ? d_consumed + done : nullptr, st);
-            if (rc == 1) break;
-            if (rc != TAMP_OK) return rc;
+            rc = launch_decompress_long(ctx, d_dict, dict_len, max_wbits, d_in, d_in_off + done, d_in_len + done, d_out,
+                                        d_out_off + done, d_out_cap + done, d_out_len + done, d_status + done,
+                                        d_consumed ? d_consumed + done : nullptr, st);
+            if (rc != TAMP_OK) break;
         }
+        t_timing_outer = false;
+        if (rc != TAMP_OK && rc != 1) return rc;
         if (done == n_streams) return TAMP_OK;
     }
     const bool exact = (max_wbits & TAMP_AMD_WINDOW_BITS_EXACT) != 0;
@@ -1699,9 +1718,20 @@ long long tamp_amd_trim(int device) {
         if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
         for (auto& kv : ctx->blk_scratch)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
-        std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
-        for (auto& kv : ctx->lpt_scratch)
-            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
+        {   // expensive-first tables: a stream's enqueue lock first (a call in flight on it finishes its launches), then the map's
+            std::vector<hipStream_t> streams;
+            {
+                std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
+                for (auto& kv : ctx->lpt_scratch) streams.push_back(kv.first);
+            }
+            for (hipStream_t s2 : streams) {
+                std::lock_guard<std::mutex> enqueue(ctx->enqueue_lock(s2));
+                if (hipStreamSynchronize(s2) != hipSuccess) (void)hipGetLastError();
+                std::lock_guard<std::mutex> lpt_lock(ctx->lpt_mu);
+                auto& g = ctx->lpt_scratch[s2];
+                if (g.p) { (void)hipFree(g.p); freed += (long long)g.bytes; g.p = nullptr, g.bytes = 0; }
+            }
+        }
         std::lock_guard<std::mutex> long_lock(ctx->long_mu);  // (the long-stream decoder's chunk tables and records)
         for (auto& kv : ctx->long_scratch)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }

@@ -1846,6 +1846,13 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     }
                     break;
                 }
+                // Entry offset 15 is no offset: pass 1 writes 0xFFFFFFFF for a chain that met a position the state machine would
+                // take (none in the v1 format), the scan follows that word to entry 15 and stays there (row 15 of every table
+                // is 0xFFFFFFFF as well).  Should the invariant ever break, the stream ends with TAMP_ERROR instead of bytes.
+                if (((uint32_t)binfo & 15u) == 15u) {
+                    if (s == a.n_blocks - 1 && tid == 0) a.out_len[0] = 0, a.status[0] = kError;
+                    break;
+                }
                 wk.rd = wk.wr = (uint32_t)binfo & 15u;  // pass 3: the walk starts where the previous block's last token ended
             }
 
