@@ -188,7 +188,17 @@ __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix)
 // Length (0..16) of the common prefix of ebuf[c..c+16) and the pattern dwords P[0..3].  Branch-free: 64 lanes in
 // lockstep would walk every branch of a staged compare anyway, so all 16 bytes are fetched (five aligned dwords,
 // funnel-shifted by the byte phase) and the first differing byte is found with two 64-bit count-trailing-zeros.
+// v_ffbl_b32 as the hardware defines it: 0xFFFFFFFF for a zero operand (__builtin_ctz leaves that case undefined)
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
+#ifdef TAMP_CMP_HWUA  // (A/B: one hardware-unaligned ds_read_b128 instead of five aligned dwords + four funnel shifts)
+    const LdsU128 v = *reinterpret_cast<const LdsU128*>(ebuf + c);
+    const uint32_t x0 = v.x ^ P[0], x1 = v.y ^ P[1], x2 = v.z ^ P[2], x3 = v.w ^ P[3];
+#else
     const uint32_t* w = reinterpret_cast<const uint32_t*>(ebuf + (c & ~3u));
     const uint32_t sh = c & 3u;
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
@@ -196,6 +206,19 @@ __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c
     const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ P[1];
     const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ P[2];
     const uint32_t x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ P[3];
+#endif
+#ifndef TAMP_CMP_STAGED
+    // Round 6: no branch at all.  First set bit of each difference dword (all ones when it has none), the dword's bit offset
+    // added with unsigned saturation (v_add_u32 ... clamp keeps "none" at all ones), the smallest of the four: 4 ffbl + 3 add +
+    // min3 + min + shift = 10 instructions behind the xors where the staged form ran 6 + 13 in nearly every lock-step
+    // iteration (some lane's first eight bytes agree) with two exec-mask regions: synthetic 5.96 -> 5.81 ms, prose 9.96 -> 9.63,
+    // markup 9.88 -> 9.53, Python sources 22.24 -> 21.74 (profiles/ab/r6_experiments.log).
+    const uint32_t t0 = ffbl_or_ones(x0);
+    const uint32_t t1 = __builtin_elementwise_add_sat(ffbl_or_ones(x1), 32u);
+    const uint32_t t2 = __builtin_elementwise_add_sat(ffbl_or_ones(x2), 64u);
+    const uint32_t t3 = __builtin_elementwise_add_sat(ffbl_or_ones(x3), 96u);
+    return min(min(min(t0, t1), min(t2, t3)) >> 3, 16u);
+#endif
     const uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
     const uint32_t nlo = (uint32_t)__builtin_ctzll(lo | (1ull << 63)) >> 3;          // 0..7 (7 also when lo == 0)
     const uint32_t nhi = 8u + ((uint32_t)__builtin_ctzll(hi | (1ull << 63)) >> 3);   // 8..15
@@ -869,6 +892,14 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
     constexpr uint32_t kRem = 16 - HB, kBuckets = 1u << HB;
+    // Round 6, the W = 2^10 build of the default parse: index entries laid out for ONE subtraction + ONE compare per candidate,
+    //     rest of the bigram (5 bits) << 27 | buffer position (12 bits) << 15 | third byte | low 7 bits of the fourth << 8
+    // With x = entry ^ (the query's rest << 27 | its own bytes 2, 3) and y = x - (q << 15):  y < (W - 1) << 15  <=>  same
+    // bigram AND 0 <= position - q <= W - 2 (a position in front of the window borrows into the rest field; a foreign rest
+    // leaves at least 2^27 - (q << 15) >= 3073 << 15, q <= 1,024).  y >> 15 is the distance from the oldest window byte, the low
+    // 15 bits classify 2- / 3-byte candidates and the ones worth a compare -- where the 16 + 11 + 5 layout spent a masked
+    // subtraction, a three-way bit operation, two compares and a scalar AND.
+    constexpr bool kEntV2 = PACKED && !LAZY && WSCAN == 1024 && HB == 11;
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // LOOP builds: this workgroup's claim on the work counter (next stream, end of the claim, the stream in hand, start of
@@ -1249,7 +1280,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         if constexpr (RUNS) { if (nruns) keep = !((rbits[c >> 5] >> (c & 31u)) & 1u); }
                         if (keep) {
                             const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
-                            if (PACKED)
+                            if (kEntV2)
+                                ent[(old >> sh) & 0xFFFFu] = ((mx & ((1u << kRem) - 1)) << 27) | (c << 15) | ((b4 >> 16) & 0x7FFFu);
+                            else if (PACKED)
                                 ent[(old >> sh) & 0xFFFFu] = c | entry_payload<kRem>(b4, mx);
                             else
                                 ent16[(old >> sh) & 0xFFFFu] = (uint16_t)c;
@@ -1355,7 +1388,58 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         uint32_t sl = qstart[q], wrapmask = 0;
                         uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
                         TAMP_FINE(f0);
-                        if constexpr (!LAZY) {
+                        if constexpr (kEntV2) {
+                            constexpr uint32_t Ws = WSCAN;
+                            const uint32_t pkx = ((mix16(P[0] & 0xFFFFu) & ((1u << kRem) - 1)) << 27) | ((P[0] >> 16) & 0x7FFFu);
+                            const uint32_t qs = q << 15;
+                            const uint32_t nb = ~(q + e_wp);  // W - window index of the candidate at distance d = ((nb - d) & (W - 1)) + 1
+                            const uint32_t* pe = ent + sl;
+                            const uint32_t* const pe_end = ent + s_hi;
+#ifdef TAMP_PROF
+                            // instruction-count experiments: run the (idempotent) loop twice, count the difference
+                            uint32_t n16_first = 0;
+                            for (uint32_t rep = 0; rep < ((a.dbg & 0x100u) ? 2u : 1u); rep++) {
+                            if (rep) { n16_first = n16; pe = ent + sl; e_next = *pe; }
+#endif
+                            while (pe < pe_end) {
+#ifdef TAMP_PROF
+                                niter++;
+#endif
+                                const uint32_t e = e_next;
+                                pe++;
+                                e_next = *pe;  // one past the range at the end: harmless
+                                const uint32_t y = (e ^ pkx) - qs;
+                                if (y < ((Ws - 1) << 15)) {  // in the window and the same bigram
+                                    const uint32_t d = y >> 15;
+                                    const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
+                                    const uint32_t low = y & 0x7FFFu;
+                                    uint32_t len = (low & 0xFFu) ? 2u : 3u;
+#ifdef TAMP_PROF
+                                    if (low == 0 && !(a.dbg & 0x8000u)) {
+                                        len = prefix_len16(ebuf, q + d, P);
+                                        if (a.dbg & 0x1000000u) {  // (the compare once more -- same result -- for its exact count)
+                                            asm volatile("" ::: "memory");
+                                            len = max(len, prefix_len16(ebuf, q + d, P));
+                                        }
+                                    } else if (low == 0) len = 4u;
+#else
+                                    if (low == 0) len = prefix_len16(ebuf, q + d, P);  // the next two bytes agree too (7 bits of the second)
+#endif
+                                    // (the wrap zone and the key: as in the generic loop below)
+                                    if (t < 16 && len >= t) {
+                                        wrapmask |= 1u << t;
+                                    } else {
+                                        if constexpr (RUNS) n16 += len >> 4;
+                                        const uint32_t lim_i = ((nb - d) & (Ws - 1)) + 1;
+                                        key = max(key, (min(len, min(cap_len, lim_i)) << 16) | lim_i);
+                                    }
+                                }
+                            }
+#ifdef TAMP_PROF
+                            if (rep) n16 = n16_first;
+                            }
+#endif
+                        } else if constexpr (!LAZY) {
                             const uint32_t Ws = WSCAN ? WSCAN : W;  // (see the template parameter)
 #ifdef TAMP_PROF
                             // instruction-count experiments: run the (idempotent) loop twice, count the difference
