@@ -195,7 +195,10 @@ __device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x) {
     return r;
 }
 __device__ __forceinline__ uint32_t prefix_len16(const uint8_t* ebuf, uint32_t c, const uint32_t (&P)[4]) {
-#ifdef TAMP_CMP_HWUA  // (A/B: one hardware-unaligned ds_read_b128 instead of five aligned dwords + four funnel shifts)
+#ifndef TAMP_CMP_ALIGNED
+    // Round 6: ONE hardware-unaligned ds_read_b128 (gfx950's LDS serves it) instead of five aligned dwords + four funnel shifts:
+    // with the rest of the loop slimmed down the LDS pipe has the room (synthetic 5.64 -> 5.51 ms; in rounds 1-2 it was the bound:
+    // +7 %).  profiles/ab/r6_experiments.log
     const LdsU128 v = *reinterpret_cast<const LdsU128*>(ebuf + c);
     const uint32_t x0 = v.x ^ P[0], x1 = v.y ^ P[1], x2 = v.z ^ P[2], x3 = v.w ^ P[3];
 #else
@@ -1410,8 +1413,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                 e_next = *pe;  // one past the range at the end: harmless
                                 const uint32_t y = (e ^ pkx) - qs;
                                 if (y < ((Ws - 1) << 15)) {  // in the window and the same bigram
-                                    const uint32_t d = y >> 15;
-                                    const uint32_t t = Ws - d;  // bytes before the candidate reaches the newest byte
+                                    const uint32_t d = y >> 15;  // Ws - d bytes before the candidate reaches the newest byte
                                     const uint32_t low = y & 0x7FFFu;
                                     uint32_t len = (low & 0xFFu) ? 2u : 3u;
 #ifdef TAMP_PROF
@@ -1425,9 +1427,11 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #else
                                     if (low == 0) len = prefix_len16(ebuf, q + d, P);  // the next two bytes agree too (7 bits of the second)
 #endif
-                                    // (the wrap zone and the key: as in the generic loop below)
-                                    if (t < 16 && len >= t) {
-                                        wrapmask |= 1u << t;
+                                    // (the wrap zone and the key: as in the generic loop below.  One test: the compare reaches the
+                                    // newest byte iff d + len >= Ws; a 16-byte hit exactly 16 bytes in front of it -- exact as it
+                                    // stands -- goes the same way and comes out of the wrapped compare with the same 16)
+                                    if (d + len >= Ws) {
+                                        wrapmask |= 1u << (Ws - d);
                                     } else {
                                         if constexpr (RUNS) n16 += len >> 4;
                                         const uint32_t lim_i = ((nb - d) & (Ws - 1)) + 1;
