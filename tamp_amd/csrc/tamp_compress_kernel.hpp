@@ -392,7 +392,6 @@ struct Walk {
     // index" among the candidates >= the first match -- which one search with the whole look-ahead finds directly.
     // Candidate rounds [4 * g0, 4 * g1) of the search (a round = one candidate per lane, 64 apart): the best key of this
     // wavefront's lanes.  key = length << 16 | ~candidate: longest, ties -> lowest candidate, whatever the order of evaluation.
-#ifndef TAMP_OLD_EXT_SEARCH
     // Round 5: the filter looks at the candidate's FIRST four bytes as well as at the four around the current end (a 4-byte
     // filter alone passes two to five false candidates per search in 1 KiB of text, and each cost every lane of its
     // wavefront a serial byte-by-byte verification), and whatever passes is compared by the whole wavefront at once -- four
@@ -455,49 +454,6 @@ struct Walk {
         }
         return uni(key);
     }
-#else
-    __device__ __forceinline__ uint32_t ext_search_rounds(uint32_t avail, uint32_t g0, uint32_t g1) const {
-        const uint32_t pos = ext_pos, cnt = ext_count;
-        const uint32_t maxp = min(cnt + avail, minp + 11 + kExtExtraMax);
-        // filter: the candidate's bytes cnt-3 .. cnt must equal the last three consumed bytes + the next input byte
-        // (the consumed bytes ARE the pattern: input [rd-cnt, rd) == window[pos, pos+cnt))
-        const uint32_t tail4 = uni(lds_u32_unaligned(ebuf, W + rd - 3));
-        const uint32_t nextb = tail4 >> 24;
-        const uint32_t wpv = wp();
-        uint32_t key = 0;
-        // 16 rounds per pass over 1,024 window positions, four at a time: independent LDS reads (one round trip), then
-        // the survivors are verified
-        for (uint32_t c0 = pos + lane; c0 + cnt + 1 <= W; c0 += 16 * kWave) {
-            for (uint32_t g = g0; g < g1; g++) {
-                if (4 * g * kWave >= W) break;  // (2^8 / 2^9 windows: 4 / 8 candidates per lane cover the window)
-                // (uniform: no candidate of this and the later rounds is in range.  What a search costs is the instructions
-                // it issues, and the candidates start at `pos`, half way up the window on average.)
-                if (uni(c0 - (uint32_t)lane) + 4 * g * kWave + cnt + 1 > W) break;
-                uint32_t hits = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t c = c0 + (4 * g + j) * kWave;
-                    const bool valid = c + cnt + 1 <= W;
-                    const uint32_t r = ((valid ? c : pos) + cnt - 3 - wpv) & mask;  // oldest-first offset of byte cnt-3
-                    bool hit = lds_u32_unaligned(ebuf, wr + r) == tail4;
-                    if (r > W - 4) hit = ebuf[wr + ((r + 3) & mask)] == nextb;  // the four bytes straddle the write cursor
-                    hits |= (uint32_t)(valid && hit) << j;
-                }
-                while (hits) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(hits);
-                    hits &= hits - 1;
-                    const uint32_t c = c0 + (4 * g + j) * kWave;
-                    if (c != pos && common_l(c, pos, cnt, true) < cnt) continue;  // (the current position matches itself)
-                    const uint32_t cmax = min(maxp, W - c);
-                    const uint32_t len = cnt + 1 + common_l(c + cnt + 1, 1, cmax - cnt - 1, false);
-                    key = max(key, (len << 16) | (0xFFFFu - c));
-                }
-            }
-        }
-        return wave_max_u32(key);
-    }
-
-#endif
 
     enum : uint32_t { kCoopCmd = 17, kCoopA = 1, kCoopB = 2, kCoopC = 3, kCoopD = 4, kCoopE = 18, kCoopF = 19, kCoopKey = 8 };  // ctl words (free during the walk)
     enum : uint32_t { kCmdEnd = 0, kCmdExtSearch = 1, kCmdBest = 2 };
