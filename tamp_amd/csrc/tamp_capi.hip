@@ -101,6 +101,7 @@ struct DeviceCtx {
     // launch's kernels find the previous one's done with it; a stream-ordered allocation per launch cost 0.7 ms of host time)
     std::mutex long_mu;
     std::map<hipStream_t, HostPipe::Grow> long_scratch;  // one long stream decoded by the whole device: chunk tables, records
+    std::map<hipStream_t, HostPipe::Grow> long_maps;     // ... and the groups' tail maps (groups x window x 2 bytes)
     std::mutex lpt_mu;
     std::map<hipStream_t, HostPipe::Grow> lpt_scratch;
     // one enqueue at a time per HIP stream for the compress launches that keep per-stream scratch (the expensive-first
@@ -854,30 +855,45 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     }
     if (dbg_long) fprintf(stderr, "[tamp_amd long decode] %zu groups, %llu tokens, %llu bytes out\n", G, (unsigned long long)tk, (unsigned long long)v);
     if (chain) {
-        // all groups in ONE launch: a workgroup per group resolves what lies inside the group at once and waits only for the
-        // bytes of the group in front (tamp_long_resolve_kernel); the table and the flags sit behind the group tables above
+        // every group by a workgroup of its own, no workgroup waiting for another (tamp_decompress_long_kernel.hpp, step 3):
+        // tail maps, their composition by one workgroup, finish.  The group table sits behind the tables above, the maps
+        // (G x W x 2 bytes) in a buffer of their own.
         uint8_t* const ctab = d_win + 4 * (size_t)(1u << 15);
         LongGroup* const d_groups = reinterpret_cast<LongGroup*>(ctab);
-        uint32_t* const d_flags = reinterpret_cast<uint32_t*>(d_groups + G);
-        uint32_t* const d_err = d_flags + G;
+        uint16_t* d_maps = nullptr;
+        const size_t n_blocks = (G + kLongScanBlock - 1) / kLongScanBlock;
+        {
+            std::lock_guard<std::mutex> lock(ctx->long_mu);
+            DeviceCtx::HostPipe::Grow& mb = ctx->long_maps[st];
+            // (behind the groups' maps: the blocks' maps and the window in front of every block)
+            if (mb.need((G + n_blocks) * (size_t)W * 2 + n_blocks * (size_t)W + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
+            d_maps = static_cast<uint16_t*>(mb.p);
+        }
+        uint16_t* const d_blockmap = d_maps + G * (size_t)W;
+        uint8_t* const d_blockwin = reinterpret_cast<uint8_t*>(d_blockmap + n_blocks * (size_t)W);
         {
             std::vector<LongGroup> tabv(G);
             for (size_t k = 0; k < G; k++) tabv[k] = LongGroup{groups[k].v0, groups[k].tok0, groups[k].ntok, groups[k].nout, 0};
             HIP_OK(hipMemcpyAsync(d_groups, tabv.data(), G * sizeof(LongGroup), hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemsetAsync(d_flags, 0, (G + 1) * 4, st));
             HIP_OK(hipStreamSynchronize(st));
         }
         LongResolveArgs ra;
-        ra.recs = recs, ra.groups = d_groups, ra.out = out, ra.dict0 = dict0, ra.flags = d_flags, ra.err = d_err, ra.wbits = wbits;
+        ra.recs = recs, ra.groups = d_groups, ra.out = out, ra.dict0 = dict0, ra.tailmap = d_maps, ra.wbits = wbits;
         ra.n_groups = (uint32_t)G;
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_long_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)long_resolve_lds()));
-        hipLaunchKernelGGL(tamp_long_resolve_kernel, dim3((uint32_t)G), dim3(256), long_resolve_lds(), st, ra);
-        uint32_t err = 1;
-        HIP_OK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        if (dbg_long) fprintf(stderr, "[tamp_amd long decode] chained resolve: err %u\n", err);
-        if (err) { timing_end(st); return 1; }  // (a wait that gave up: the exact decoder writes the stream again)
+        auto k_tails = tamp_long_resolve_kernel<1>;
+        auto k_finish = tamp_long_resolve_kernel<2>;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tails), hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_resolve_lds()));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_resolve_lds()));
+        LongScanArgs sc;
+        sc.r = ra, sc.blockmap = d_blockmap, sc.blockwin = d_blockwin, sc.n_blocks = (uint32_t)n_blocks;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_long_tail_scan_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * W)));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_long_tail_scan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * W)));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(tamp_long_tail_scan_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * W)));
+        hipLaunchKernelGGL(k_tails, dim3((uint32_t)G), dim3(256), long_resolve_lds(), st, ra);
+        hipLaunchKernelGGL(tamp_long_tail_scan_kernel<0>, dim3((uint32_t)n_blocks), dim3(kLongScanThreads), 4 * W, st, sc);
+        hipLaunchKernelGGL(tamp_long_tail_scan_kernel<1>, dim3(1), dim3(kLongScanThreads), 2 * W, st, sc);
+        hipLaunchKernelGGL(tamp_long_tail_scan_kernel<2>, dim3((uint32_t)n_blocks), dim3(kLongScanThreads), 2 * W, st, sc);
+        hipLaunchKernelGGL(k_finish, dim3((uint32_t)G), dim3(256), long_resolve_lds(), st, ra);
         hipLaunchKernelGGL(tamp_long_finish_kernel, dim3(1), dim3(1), 0, st, d_out_len, d_status, d_consumed, (uint32_t)v, n);
         timing_end(st);
         HIP_OK(hipGetLastError());
@@ -1734,6 +1750,8 @@ long long tamp_amd_trim(int device) {
         }
         std::lock_guard<std::mutex> long_lock(ctx->long_mu);  // (the long-stream decoder's chunk tables and records)
         for (auto& kv : ctx->long_scratch)
+            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
+        for (auto& kv : ctx->long_maps)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
     }
     {   // the host-memory pipeline: pinned staging of non-tiling output slabs (it grows with the largest extent ever staged,

@@ -4,7 +4,7 @@
 // Replaces, for one stream, tamp_decompressor_decompress (tamp/_c_src/tamp/decompressor.c:371-578) where its token loop is
 // position-independent: the v1 format without a dictionary reset -- a literal is 1 + literal bits, a match is the flag, a
 // prefix code (decompressor.c:52-104) and window bits, FLUSH pads to the byte boundary (:501-514), and none of it depends
-// on the window.  A wavefront per stream decodes such a stream at ~700 cycles per token (7 MB/s; this path: 2.3 GB/s); here
+// on the window.  A wavefront per stream decodes such a stream at ~700 cycles per token (7 MB/s; this path: 10 GB/s); here
 //
 //   1. the compressed bits are cut into chunks of kLongChunkBits and a lane per chunk parses from a GUESSED start; the
 //      position where it leaves its chunk is the next chunk's start for the next round (tamp_long_sync_kernel; the 64 chunks
@@ -13,11 +13,12 @@
 //      host's loop.  Unchanged guesses everywhere = all right (tests/test_host_logic.py restates this on the CPU);
 //   2. a lane per chunk counts its tokens and bytes, the host cuts the chunks into groups of at most kLongGroupOut output
 //      bytes, a lane per chunk writes the split decoder's 32-bit records (tamp_long_parse_kernel);
-//   3. ONE launch resolves all groups, a workgroup each (tamp_long_resolve_kernel below): everything inside a group at once,
-//      the bytes it takes from the window in front of it when the group in front has stored its own.  A group is a stream
-//      whose window is rotated so that its write cursor starts at 0 (window offsets are rotated with it when the records are
-//      written).  (TAMP_AMD_LONGDEC_CHAIN=0: groups of kSplitMaxOut bytes through the split decoder's RESOLVE, one launch
-//      after the other, each with the W output bytes in front of it as its "dictionary".)
+//   3. the groups are resolved by a workgroup each, all at once, and none waits for another: what a group takes from the
+//      stream in front of it is the WINDOW as it stood when the group began, and those windows follow from the groups' tail
+//      maps by one cheap pass (tails / scan / finish, see tamp_long_resolve_kernel below).  A group is a stream whose window is
+//      rotated so that its write cursor starts at 0 (window offsets are rotated with it when the records are written).
+//      (TAMP_AMD_LONGDEC_CHAIN=0: groups of kSplitMaxOut bytes through the split decoder's RESOLVE, one launch after the
+//      other, each with the W output bytes in front of it as its "dictionary".)
 //
 // Anything else -- extended format, dictionary reset, an out-of-bounds offset, an output buffer that is too small, a sync
 // that does not settle -- is left to the exact decoders: the launcher falls back before anything has been written.
@@ -194,15 +195,23 @@ __global__ void tamp_long_finish_kernel(uint32_t* out_len, int8_t* status, uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Step 3 in ONE launch: a workgroup per group, all groups at once.  What a group needs from the group in front of it are only
-// the bytes its copies take from the window as it stood when the group began; everything inside the group -- the split decoder's
-// token pass, byte pass and pointer jumping (tamp_decode_resolve_kernel, without lags: the v1 format has none) -- does not wait.
-// A byte whose source lies in front of the group becomes EXTERNAL (bit 15 of its pointer, the rotated window index below it),
-// pointer jumping carries that mark to every byte that ends there, and only then the workgroup waits for the flag of the group in
-// front, fetches its external bytes from the output, stores its own bytes and raises its flag: the groups' serial chain is one
-// flag, one gather and one store each instead of a kernel.  Workgroups are dispatched in order (per XCD as well: the oldest
-// unfinished group is always resident), so the wait cannot deadlock; it is bounded all the same, and a group that gives up sets
-// `err` -- the launcher then hands the stream to the exact decoder.
+// Step 3: every group of at most kLongGroupOut output bytes by a workgroup of its own, and NO workgroup waits for another
+// (round 6; round 5 chained the groups through one flag each inside one launch -- ~13 us per link, 39 ms of a 100 MB stream
+// was that chain, and its freedom from deadlock rested on the order in which workgroups are dispatched).
+// What a group needs from the stream in front of it is only the WINDOW as it stood when the group began: the last W bytes
+// written.  Everything inside the group -- the split decoder's token pass, byte pass and pointer jumping
+// (tamp_decode_resolve_kernel, without lags: the v1 format has none) -- is independent of it: a byte whose source lies in front
+// of the group becomes EXTERNAL (bit 15 of its pointer, the index of the byte in that window, oldest first, below it) and
+// pointer jumping carries the mark to every byte that ends there.  Three launches:
+//   tails   (tamp_long_resolve_kernel<1>)  a workgroup per group resolves the group and writes its TAIL MAP: for each of the W
+//           bytes of the window as the group leaves it, the byte itself or "byte j of the window in front" (a group shorter
+//           than W passes the rest of that window on the same way);
+//   scan    (tamp_long_tail_scan_kernel)   the maps compose: window after group g = map g applied to the window after group
+//           g-1, starting from the fresh decoder's window.  One workgroup walks the groups, W gathers in LDS per step, and
+//           stores every group's last bytes where they belong in the output (~0.3 us a group);
+//   finish  (tamp_long_resolve_kernel<2>)  a workgroup per group resolves it again, takes its external bytes from the output
+//           in front of it -- written by the scan launch, or the fresh window where the stream is younger than W -- and stores.
+// The resolve runs twice (compute, ~50 us a group, all groups at once) so that nothing of it has to travel through HBM.
 // ---------------------------------------------------------------------------------------------------------------
 struct LongGroup {
     unsigned long long v0;  // output position of the group's first byte
@@ -213,8 +222,7 @@ struct LongResolveArgs {
     const LongGroup* groups;
     uint8_t* out;            // the stream's output
     const uint8_t* dict0;    // the window of a fresh decoder (custom dictionary or the seeded default)
-    uint32_t* flags;         // one per group, zeroed: 1 = its bytes are in `out`
-    uint32_t* err;
+    uint16_t* tailmap;       // n_groups x W: byte k of the window behind group g = the byte itself, or kLongExt | j (see above)
     uint32_t wbits;
     uint32_t n_groups;
 };
@@ -224,6 +232,7 @@ constexpr uint32_t kLongExt = 0x8000u;
 constexpr uint32_t kLongGroupOut = 32768;
 __host__ __device__ constexpr uint32_t long_resolve_lds() { return (kLongGroupOut + 16) + 2 * kLongGroupOut + 128; }
 
+template <int PHASE>  // 1 = tail maps, 2 = finish
 __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs ra) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t nt = 256, BPT = 4;
@@ -357,58 +366,39 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
             if (!__syncthreads_or((int)any)) break;
         }
     }
-    // which of this thread's bytes are external: noted BEFORE the wait (behind it, a scan of all positions with a load inside
-    // was 13 us of the 26 a 32 KiB group spent in the serial part)
-    constexpr uint32_t NE = kLongGroupOut / (32 * nt);
-    uint32_t em[NE] = {};
-    if (n_out) {
-#pragma unroll
-        for (uint32_t w = 0; w < NE; w++) {
-            if (w * 32 * nt < n_out) {
-                for (uint32_t i = 0; i < 32; i++) {
-                    const uint32_t p = (w * 32 + i) * nt + tid;
-                    if (p < n_out && (src[p] & kLongExt)) em[w] |= 1u << i;
-                }
+    if constexpr (PHASE == 1) {
+        // the window as this group leaves it, oldest byte first: its own last bytes, and in front of them -- a group shorter
+        // than W -- what is left of the window it found
+        uint16_t* const tm = ra.tailmap + (size_t)g * W;
+        for (uint32_t k = tid; k < W; k += nt) {
+            uint32_t e;
+            if (n_out + k >= W) {
+                const uint32_t p = n_out + k - W;
+                const uint32_t sp = src[p];
+                e = (sp & kLongExt) ? sp : (uint32_t)outb[p];
+            } else {
+                e = kLongExt | (n_out + k);
             }
+            tm[k] = (uint16_t)e;
         }
-    }
-    // ---- the group in front: wait for its bytes ----
-    bool failed = false;
-    if (g > 0) {
-        if (tid == 0) {
-            uint32_t spins = 0;
-            // (relaxed: an acquire at agent scope invalidates the XCD's whole L2 -- 1,891 of them per 30 MB slowed every
-            // workgroup's record reads, 229 ms against 92 for launches in a row; the bytes behind the flag are fetched with
-            // agent-scope atomic loads below, which do not look at stale lines either)
-            while (__hip_atomic_load(ra.flags + (g - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                if (__hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > (1u << 24)) {
-                    __hip_atomic_store(ra.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            ctl[13] = __hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        failed = ctl[13] != 0;
-    }
-    if (!failed && n_out) {
+        return;
+    } else {
+        if (!n_out) return;
+        // external bytes: the window in front of the group -- the output behind v0 - W (the scan launch stored every group's last
+        // bytes), or, where the stream is younger than W, the fresh decoder's window at that ring index
         const unsigned long long v0 = gr.v0;
         const uint32_t wp0 = (uint32_t)(v0 & mask);
         uint8_t* const out = ra.out + v0;
-#pragma unroll
-        for (uint32_t w = 0; w < NE; w++) {
-            for (uint32_t m = em[w]; m;) {
-                const uint32_t i = (uint32_t)__builtin_ctz(m);
-                m &= m - 1;
-                const uint32_t p = (w * 32 + i) * nt + tid;
-                const uint32_t j = (uint32_t)src[p] & 0x7FFFu;  // j-th oldest byte of the window in front of the group
+        for (uint32_t p = tid; p < n_out; p += nt) {
+            const uint32_t sp = src[p];
+            if (sp & kLongExt) {
+                const uint32_t j = sp & 0x7FFFu;  // j-th oldest byte of the window in front of the group
                 uint32_t b;
                 if (v0 >= W) {
-                    b = __hip_atomic_load(ra.out + (v0 - W + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b = ra.out[v0 - W + j];
                 } else {
                     const uint32_t r = (j + wp0) & mask;
-                    b = r < (uint32_t)v0 ? __hip_atomic_load(ra.out + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ra.dict0[r];
+                    b = r < (uint32_t)v0 ? ra.out[r] : ra.dict0[r];
                 }
                 outb[p] = (uint8_t)b;
             }
@@ -421,9 +411,99 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
         for (uint32_t i = tid; i < ndw; i += nt) out32[i] = lds_u32_unaligned(outb, head + 4 * i);
         for (uint32_t i = head + 4 * ndw + tid; i < n_out; i += nt) out[i] = outb[i];
     }
-    __threadfence();
+}
+
+// The tail maps composed.  window after group g = map g applied to the window after group g - 1, starting from the fresh
+// decoder's window -- a chain over the groups, made short by blocks of kLongScanBlock groups (round 6; one workgroup walking all
+// 3,050 groups of a 100 MB stream took 4.9 ms of the call's 9.4, 1.6 us a step):
+//   MODE 0  a workgroup per block composes its groups' maps into ONE map of the block (the identity pushed through them: an
+//           entry stays "byte j of the window in front of the block" or becomes a byte), all blocks at once;
+//   MODE 1  ONE workgroup walks the block maps: the window in front of every block (n_blocks x W bytes);
+//   MODE 2  a workgroup per block walks its groups again from that window and stores every group's last bytes where they
+//           belong in the output: the finish launch reads its external bytes from there.
+// A step is W gathers in LDS (two buffers), the next map prefetched into registers in front of the barrier.
+constexpr uint32_t kLongScanThreads = 1024;
+constexpr uint32_t kLongScanBlock = 64;
+struct LongScanArgs {
+    LongResolveArgs r;
+    uint16_t* blockmap;   // n_blocks x W
+    uint8_t* blockwin;    // n_blocks x W: the window in front of block b
+    uint32_t n_blocks;
+};
+template <int MODE>
+__global__ void __launch_bounds__(kLongScanThreads) tamp_long_tail_scan_kernel(LongScanArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const LongResolveArgs& ra = sa.r;
+    const uint32_t W = 1u << ra.wbits;
+    const uint32_t tid = threadIdx.x, nt = kLongScanThreads;
+    constexpr uint32_t kPer = (1u << 15) / kLongScanThreads;  // map entries a thread holds at the largest window
+    const uint32_t per = (W + nt - 1) / nt;                   // 1 .. kPer
+    // two buffers of W entries: bytes (MODE 1, 2) or map entries (MODE 0)
+    typedef typename std::conditional<MODE == 0, uint16_t, uint8_t>::type Ent;
+    Ent* const buf0 = reinterpret_cast<Ent*>(smem);
+    Ent* const buf1 = buf0 + W;
+    // what is walked: the block maps (MODE 1: one workgroup, all of them) or this block's group maps
+    const uint32_t first = MODE == 1 ? 0u : blockIdx.x * kLongScanBlock;
+    const uint32_t count = MODE == 1 ? sa.n_blocks : min(kLongScanBlock, ra.n_groups - first);
+    const uint16_t* const maps = MODE == 1 ? sa.blockmap : ra.tailmap + (size_t)first * W;
+    __shared__ unsigned long long s_vend[kLongScanBlock];
+    __shared__ uint32_t s_nout[kLongScanBlock];
+    if constexpr (MODE == 2) {
+        if (tid < count) {
+            const LongGroup gr = ra.groups[first + tid];
+            s_vend[tid] = gr.v0 + gr.nout, s_nout[tid] = gr.nout;
+        }
+    }
+    for (uint32_t k = tid; k < W; k += nt) {
+        if constexpr (MODE == 0) buf0[k] = (Ent)(kLongExt | k);  // the identity
+        else if constexpr (MODE == 1) buf0[k] = ra.dict0[k];     // (group 0 starts at v0 = 0: byte j of its window is ring index j)
+        else buf0[k] = sa.blockwin[(size_t)blockIdx.x * W + k];
+    }
+    uint16_t cur[kPer], nxt[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+        const uint32_t k = i * nt + tid;
+        cur[i] = (i < per && k < W && count) ? maps[k] : 0;
+        nxt[i] = 0;
+    }
     __syncthreads();
-    if (tid == 0 && !failed) __hip_atomic_store(ra.flags + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t g = 0; g < count; g++) {
+        const Ent* const src = (g & 1) ? buf1 : buf0;
+        Ent* const dst = (g & 1) ? buf0 : buf1;
+        if (g + 1 < count) {
+            const uint16_t* const tm = maps + (size_t)(g + 1) * W;
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; i++) {
+                const uint32_t k = i * nt + tid;
+                if (i < per && k < W) nxt[i] = tm[k];
+            }
+        }
+        if constexpr (MODE == 1) {  // the window in front of block g
+            for (uint32_t k = tid; k < W; k += nt) sa.blockwin[(size_t)g * W + k] = src[k];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; i++) {
+            const uint32_t k = i * nt + tid;
+            if (i < per && k < W) {
+                const uint32_t e = cur[i];
+                const Ent b = (e & kLongExt) ? src[e & 0x7FFFu] : (Ent)e;
+                dst[k] = b;
+                if constexpr (MODE == 2) {
+                    // window byte k is output byte vend - W + k -- when the stream is that old, and when this group wrote any of
+                    // it (an empty group leaves the bytes where the group in front stored them)
+                    const unsigned long long vend = s_vend[g];
+                    if (s_nout[g] && vend + k >= W) ra.out[vend + k - W] = (uint8_t)b;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; i++) cur[i] = nxt[i];
+        __syncthreads();
+    }
+    if constexpr (MODE == 0) {
+        const Ent* const fin = (count & 1) ? buf1 : buf0;
+        for (uint32_t k = tid; k < W; k += nt) sa.blockmap[(size_t)blockIdx.x * W + k] = fin[k];
+    }
 }
 
 }  // namespace tamp_amd
