@@ -377,21 +377,26 @@ def decompress(data: bytes, *args, **kwargs) -> bytearray:
     library decodes ONE long stream with the whole device; everything else -- and whatever that call does
     not finish with the normal end-of-input status -- takes the decoder object below."""
     blob = bytes(data)
-    if len(blob) >= ONE_SHOT_BLOCK_MIN and not args and set(kwargs) <= {"dictionary"} and (blob[0] & 3) == 0:
+    if len(blob) >= ONE_SHOT_BLOCK_MIN and not args and set(kwargs) <= {"dictionary"} and (blob[0] & 1) == 0:
         from .batch import decompress_batch
         # Room for the worst case at once (a call that runs out of room would take the one-wavefront decoder to find that
         # out): the densest v1 token is a 15-byte match in 7 + 8 bits (window 2^8, compressor.c:33-36) -- 8 bytes per byte.
-        # A blob whose worst case does not fit the 32-bit capacity, or that the device cannot hold 9 x of, takes the
+        # The extended format has no useful bound (an RLE token is 241 bytes in 14 bits): 8 x is tried, then 64 x.
+        # A blob whose room does not fit the 32-bit capacity, or that the device cannot hold that much of, takes the
         # streaming object below, as every input did before this shortcut existed.
-        cap = 8 * len(blob) + 64
-        if len(blob) <= ONE_SHOT_MAX_DECODE_IN and cap <= 0xFFFFFFFF:
+        for factor in ((8,) if not blob[0] & 2 else (8, 64)):
+            cap = factor * len(blob) + 64
+            if len(blob) > ONE_SHOT_MAX_DECODE_IN or cap > 0xFFFFFFFF:
+                break
             try:
                 r = decompress_batch([blob], out_cap=cap, dictionary=kwargs.get("dictionary"))
             except (MemoryError, OverflowError, _lib.NativeLibraryError):  # (the object below reports what is really wrong)
-                r = None
-            if r is not None and int(r.status[0]) == _lib.INPUT_EXHAUSTED:
+                break
+            if int(r.status[0]) == _lib.INPUT_EXHAUSTED:
                 o, n = int(r.out_off[0]), int(r.out_len[0])
                 return bytearray(memoryview(r.out)[o : o + n])  # (one copy of the bytes, not two)
+            if int(r.status[0]) != _lib.OUTPUT_FULL:
+                break
     with BytesIO(blob) as f:
         d = Decompressor(f, *args, **kwargs)
         return d.read()

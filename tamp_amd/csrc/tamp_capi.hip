@@ -102,6 +102,7 @@ struct DeviceCtx {
     std::mutex long_mu;
     std::map<hipStream_t, HostPipe::Grow> long_scratch;  // one long stream decoded by the whole device: chunk tables, records
     std::map<hipStream_t, HostPipe::Grow> long_maps;     // ... and the groups' tail maps (groups x window x 2 bytes)
+    std::map<hipStream_t, HostPipe::Grow> long_spec;     // ... extended format: the list of tokens that can lag, the lag lists
     std::mutex lpt_mu;
     std::map<hipStream_t, HostPipe::Grow> lpt_scratch;
     // one enqueue at a time per HIP stream for the compress launches that keep per-stream scratch (the expensive-first
@@ -737,15 +738,21 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     const uint32_t h0 = hdr[0], hs = 1 + (h0 & 1);
     const uint32_t wbits = ((h0 >> 5) & 7) + 8, lbits = ((h0 >> 3) & 3) + 5;
     const bool custom = (h0 >> 2) & 1, extended = (h0 >> 1) & 1, dreset = h0 & 1;
-    if (extended || dreset || (hs == 2 && hdr[1]) || wbits > (uint32_t)(max_wbits & 0x7F) || (max_wbits & 0x7F) > 15) return 1;
+    if (dreset || (hs == 2 && hdr[1]) || wbits > (uint32_t)(max_wbits & 0x7F) || (max_wbits & 0x7F) > 15) return 1;
+    if (extended && getenv("TAMP_AMD_LONGDEC_EXT") && atoi(getenv("TAMP_AMD_LONGDEC_EXT")) == 0) return 1;  // (tests: the exact decoder)
     const uint32_t W = 1u << wbits;
     if (custom && (!d_dict || dict_len < W)) return 1;
-    const uint8_t* const dict0 = custom ? d_dict : ctx->seed_dicts + ((size_t)2 << 15);  // (v1: the literal >= 7 table, decompressor.c:318-319)
+    // the fresh decoder's window: the custom dictionary, or the seeded table for the stream's literal size (v1: the literal >= 7
+    // table whatever the literal size, decompressor.c:318-319)
+    const uint32_t dict_sel = (!extended || lbits >= 7) ? 2u : (lbits == 6 ? 1u : 0u);
+    const uint8_t* const dict0 = custom ? d_dict : ctx->seed_dicts + ((size_t)dict_sel << 15);
 
     const uint64_t total_bits = 8ull * n;
-    const uint32_t N = (uint32_t)((total_bits + kLongChunkBits - 1) / kLongChunkBits);
-    // scratch: g, g_next (N + 1 each), flags (4), ntok, outb, tokbase, rot (N each), then what the groups need
-    const size_t b_tab = ((size_t)(6 * (size_t)N + 16) * 4 + 255) & ~(size_t)255;
+    const uint32_t chunk_bits = extended ? kLongChunkBitsExt : kLongChunkBits;
+    const uint32_t N = (uint32_t)((total_bits + chunk_bits - 1) / chunk_bits);
+    // scratch: g, g_next (N + 1 each), flags (4), ntok, outb, tokbase, rot (N each), the extended format's seven per-chunk tables,
+    // then what the groups need
+    const size_t b_tab = ((size_t)(14 * (size_t)N + 16) * 4 + 255) & ~(size_t)255;
     uint8_t* tab = nullptr;
     {
         std::lock_guard<std::mutex> lock(ctx->long_mu);
@@ -764,16 +771,24 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     uint32_t* const d_outb = d_ntok + N;
     uint32_t* const d_tokbase = d_outb + N;
     uint32_t* const d_rot = d_tokbase + N;
+    uint32_t* const d_nspec = d_rot + N;          // (extended format from here)
+    uint32_t* const d_specbase = d_nspec + N;
+    uint32_t* const d_chunk_lag = d_specbase + N;  // 2 N
+    uint32_t* const d_chunk_o0 = d_chunk_lag + 2 * (size_t)N;
+    uint32_t* const d_chunk_lag0 = d_chunk_o0 + N;
+    uint32_t* const d_lagbase = d_chunk_lag0 + N;
     uint32_t* const recs = reinterpret_cast<uint32_t*>(tab + b_tab);
 
     timing_begin(st);
     LongArgs la;
+    memset(&la, 0, sizeof la);
     la.in = in, la.n = n, la.first_bit = 8 * hs, la.n_chunks = N, la.wbits = wbits, la.lbits = lbits;
+    la.chunk_bits = chunk_bits, la.extended = extended ? 1u : 0u, la.nspec = d_nspec;
     la.flags = flags, la.ntok = d_ntok, la.outb = d_outb, la.tokbase = d_tokbase, la.rot = d_rot, la.recs = recs, la.write = 0;
     // start guesses: the chunk boundaries themselves (chunk 0: behind the header)
     {
         std::vector<uint32_t> init(N + 1);
-        for (uint32_t i = 0; i <= N; i++) init[i] = i * kLongChunkBits;
+        for (uint32_t i = 0; i <= N; i++) init[i] = i * chunk_bits;
         init[0] = 8 * hs;
         HIP_OK(hipMemcpyAsync(g0, init.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -806,24 +821,61 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     HIP_OK(hipMemcpyAsync(fl, flags, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     if (fl[1]) { timing_end(st); return 1; }  // an out-of-bounds offset: the exact decoder reports where
-    // groups of whole chunks: at most kSplitMaxOut output bytes and 2^20 - 1 records each
+    // Extended format: the tokens that can write fewer bytes to the window than they produce are listed (a second parse), one
+    // workgroup walks the list for window_pos at each of them, and what comes back per chunk is the lag behind it and the number
+    // of lagging tokens in it (tamp_long_wp_kernel).
+    std::vector<uint32_t> chunk_lag;  // per chunk: cumulative lag behind it, lagging tokens in it
+    uint32_t* d_lag = nullptr;        // the lag lists
+    if (extended) {
+        std::vector<uint32_t> nspec(N), specbase(N);
+        HIP_OK(hipMemcpyAsync(nspec.data(), d_nspec, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        uint64_t n_entries = 0;
+        for (uint32_t i = 0; i < N; i++) specbase[i] = (uint32_t)n_entries, n_entries += (uint64_t)nspec[i] + 1;
+        if (n_entries > 0xFFFFFFF0ull) { timing_end(st); return 1; }
+        uint32_t* d_spec = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(ctx->long_mu);
+            DeviceCtx::HostPipe::Grow& sb = ctx->long_spec[st];
+            // gap, token, bytes written per list entry; behind them the lag lists (at most one entry per listed token)
+            if (sb.need((size_t)n_entries * (3 + 2) * 4 + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
+            d_spec = static_cast<uint32_t*>(sb.p);
+        }
+        la.specbase = d_specbase, la.spec_gap = d_spec, la.spec_kl = d_spec + n_entries, la.spec_written = d_spec + 2 * n_entries;
+        d_lag = d_spec + 3 * n_entries;
+        la.chunk_lag = d_chunk_lag, la.lag = d_lag;
+        HIP_OK(hipMemcpyAsync(d_specbase, specbase.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+        la.write = 2;
+        hipLaunchKernelGGL(tamp_long_parse_kernel, dim3(lg), dim3(64), 0, st, la);
+        hipLaunchKernelGGL(tamp_long_wp_kernel, dim3(1), dim3(256), 0, st, la, (uint32_t)n_entries);
+        chunk_lag.resize(2 * (size_t)N);
+        HIP_OK(hipMemcpyAsync(chunk_lag.data(), d_chunk_lag, 2 * (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));  // (also: specbase goes out of scope)
+        for (uint32_t i = 0; i < N; i++)
+            if (chunk_lag[2 * (size_t)i + 1] > kLongLagCap) { timing_end(st); return 1; }  // (more lagging tokens in one chunk than a group lists)
+    }
+    // groups of whole chunks: at most kSplitMaxOut output bytes, 2^20 - 1 records and kLongLagCap lagging tokens each
     const char* chain_env = getenv("TAMP_AMD_LONGDEC_CHAIN");
-    const bool chain = !chain_env || atoi(chain_env) != 0;
+    const bool chain = extended || !chain_env || atoi(chain_env) != 0;
     const uint32_t group_out = chain ? kLongGroupOut : kSplitMaxOut;
-    struct Group { uint64_t v0; uint32_t tok0, ntok, nout; };
+    struct Group { uint64_t v0; uint32_t tok0, ntok, nout, lag0, nlag; uint64_t lagv0; };  // lagv0: lag of the stream in front of the group
     std::vector<Group> groups;
-    std::vector<uint32_t> tokbase(N), rot(N);
-    uint64_t v = 0, tk = 0;
+    std::vector<uint32_t> tokbase(N), rot(N), chunk_o0(N), chunk_lag0(N), lagbase(N);
+    uint64_t v = 0, tk = 0, lags = 0, cum = 0;  // output bytes, records, lagging tokens, lag so far
     {
-        Group gcur{0, 0, 0, 0};
+        Group gcur{0, 0, 0, 0, 0, 0, 0};
         for (uint32_t i = 0; i < N; i++) {
-            if (gcur.nout + outb[i] > group_out || gcur.ntok + ntok[i] > 0xFFFFFu) {
+            const uint32_t nl = extended ? chunk_lag[2 * (size_t)i + 1] : 0u;
+            if (gcur.nout + outb[i] > group_out || gcur.ntok + ntok[i] > 0xFFFFFu || gcur.nlag + nl > kLongLagCap) {
                 groups.push_back(gcur);
-                gcur = Group{v, (uint32_t)tk, 0, 0};
+                gcur = Group{v, (uint32_t)tk, 0, 0, (uint32_t)lags, 0, cum};
             }
-            tokbase[i] = (uint32_t)tk, rot[i] = (uint32_t)(gcur.v0 & (W - 1));
-            gcur.ntok += ntok[i], gcur.nout += outb[i];
-            tk += ntok[i], v += outb[i];
+            // a group's window cursor starts at (bytes WRITTEN in front of it) mod W: the output position less the lag so far
+            tokbase[i] = (uint32_t)tk, rot[i] = (uint32_t)((gcur.v0 - gcur.lagv0) & (W - 1));
+            chunk_o0[i] = (uint32_t)(v - gcur.v0), chunk_lag0[i] = (uint32_t)(cum - gcur.lagv0), lagbase[i] = (uint32_t)lags;
+            gcur.ntok += ntok[i], gcur.nout += outb[i], gcur.nlag += nl;
+            tk += ntok[i], v += outb[i], lags += nl;
+            if (extended) cum = chunk_lag[2 * (size_t)i];
         }
         groups.push_back(gcur);
     }
@@ -832,6 +884,12 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
     if (v >= cap || tk > 0xFFFFFFFFull - 4096) { timing_end(st); return 1; }
     HIP_OK(hipMemcpyAsync(d_tokbase, tokbase.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_rot, rot.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+    if (extended) {
+        HIP_OK(hipMemcpyAsync(d_chunk_o0, chunk_o0.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_chunk_lag0, chunk_lag0.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_lagbase, lagbase.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
+        la.chunk_o0 = d_chunk_o0, la.chunk_lag0 = d_chunk_lag0, la.lagbase = d_lagbase;
+    }
     la.write = 1;
     hipLaunchKernelGGL(tamp_long_parse_kernel, dim3(lg), dim3(64), 0, st, la);
     // per group: meta word, output offset and size, in tables behind the records
@@ -866,22 +924,26 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
             std::lock_guard<std::mutex> lock(ctx->long_mu);
             DeviceCtx::HostPipe::Grow& mb = ctx->long_maps[st];
             // (behind the groups' maps: the blocks' maps and the window in front of every block)
-            if (mb.need((G + n_blocks) * (size_t)W * 2 + n_blocks * (size_t)W + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
+            // (... and, extended format, in front of every group: with lags the window is not "the last W output bytes")
+            if (mb.need((G + n_blocks) * (size_t)W * 2 + (n_blocks + (extended ? G : 0)) * (size_t)W + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
             d_maps = static_cast<uint16_t*>(mb.p);
         }
         uint16_t* const d_blockmap = d_maps + G * (size_t)W;
         uint8_t* const d_blockwin = reinterpret_cast<uint8_t*>(d_blockmap + n_blocks * (size_t)W);
+        uint8_t* const d_groupwin = extended ? d_blockwin + n_blocks * (size_t)W : nullptr;
         {
             std::vector<LongGroup> tabv(G);
-            for (size_t k = 0; k < G; k++) tabv[k] = LongGroup{groups[k].v0, groups[k].tok0, groups[k].ntok, groups[k].nout, 0};
+            for (size_t k = 0; k < G; k++)
+                tabv[k] = LongGroup{groups[k].v0, groups[k].tok0, groups[k].ntok, groups[k].nout, groups[k].lag0, groups[k].nlag, 0};
             HIP_OK(hipMemcpyAsync(d_groups, tabv.data(), G * sizeof(LongGroup), hipMemcpyHostToDevice, st));
             HIP_OK(hipStreamSynchronize(st));
         }
         LongResolveArgs ra;
         ra.recs = recs, ra.groups = d_groups, ra.out = out, ra.dict0 = dict0, ra.tailmap = d_maps, ra.wbits = wbits;
+        ra.lag = d_lag, ra.groupwin = d_groupwin;
         ra.n_groups = (uint32_t)G;
-        auto k_tails = tamp_long_resolve_kernel<1>;
-        auto k_finish = tamp_long_resolve_kernel<2>;
+        auto k_tails = extended ? tamp_long_resolve_kernel<1, true> : tamp_long_resolve_kernel<1, false>;
+        auto k_finish = extended ? tamp_long_resolve_kernel<2, true> : tamp_long_resolve_kernel<2, false>;
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tails), hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_resolve_lds()));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)long_resolve_lds()));
         LongScanArgs sc;
@@ -1752,6 +1814,8 @@ long long tamp_amd_trim(int device) {
         for (auto& kv : ctx->long_scratch)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
         for (auto& kv : ctx->long_maps)
+            if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
+        for (auto& kv : ctx->long_spec)
             if (kv.second.p) { (void)hipFree(kv.second.p); freed += (long long)kv.second.bytes; kv.second.p = nullptr, kv.second.bytes = 0; }
     }
     {   // the host-memory pipeline: pinned staging of non-tiling output slabs (it grows with the largest extent ever staged,

@@ -28,24 +28,45 @@
 
 namespace tamp_amd {
 
-constexpr uint32_t kLongChunkBits = 4096;        // 512 compressed bytes per lane: at most 341 tokens, 5,115 output bytes
+constexpr uint32_t kLongChunkBits = 4096;        // v1: 512 compressed bytes per lane: at most 341 tokens, 5,115 output bytes
+// extended format: an RLE token is 12 bits for up to 241 bytes -- 128 compressed bytes per lane keep a chunk below 21 KB of output,
+// so that whole chunks still fit a group (kLongGroupOut)
+constexpr uint32_t kLongChunkBitsExt = 1024;
 constexpr uint32_t kLongEnd = 0xFFFFFFFFu;       // "the stream ended in front of this chunk"
+constexpr uint32_t kLongMaxLag = 64;             // slots of a group's lag list in LDS (a power of two: six-step binary searches) ...
+constexpr uint32_t kLongLagCap = kLongMaxLag - 1;  // ... of which a group uses at most 63: the searches count up to 32 + 16 + .. + 1
+                                                   // (more lagging tokens in ONE chunk: the exact decoder takes the stream)
 
 struct LongArgs {
     const uint8_t* in;     // the stream (header included)
     uint32_t n;            // its bytes
     uint32_t first_bit;    // 8 x header bytes
     uint32_t n_chunks;
+    uint32_t chunk_bits;   // kLongChunkBits or kLongChunkBitsExt
     uint32_t wbits, lbits;
+    uint32_t extended;     // RLE / extended-match tokens (decompressor.c:114-273)
     const uint32_t* g;     // n_chunks + 1 start positions (bits)
     uint32_t* g_next;      // sync: the next round's
     uint32_t* flags;       // [0] a guess changed  [1] an out-of-bounds offset was seen (parse)
     uint32_t* ntok;        // parse, counting: per chunk
     uint32_t* outb;
+    uint32_t* nspec;       // ... RLE / extended-match tokens of the chunk (extended format)
     const uint32_t* tokbase;  // parse, writing: first record of the chunk, rotation of its group
     const uint32_t* rot;
     uint32_t* recs;
-    uint32_t write;        // parse: 0 = count, 1 = write records
+    uint32_t write;        // parse: 0 = count, 1 = write records, 2 = list the chunk's RLE / extended-match tokens
+    // extended format: the list of tokens that may write fewer bytes to the window than they produce -- per chunk its RLE /
+    // extended-match tokens and one end marker -- walked in stream order by tamp_long_wp_kernel
+    const uint32_t* specbase;  // per chunk: index of its first list entry (nspec + 1 entries per chunk)
+    uint32_t* spec_gap;        // bytes produced by plain tokens in front of the entry (since the previous one / the chunk's start)
+    uint32_t* spec_kl;         // bytes the token produces | RLE << 31; 0 = the chunk's end marker
+    uint32_t* spec_written;    // tamp_long_wp_kernel: bytes it writes to the window (decompressor.c:162-170,266-268)
+    uint32_t* chunk_lag;       // tamp_long_wp_kernel, per chunk: cumulative lag behind it, lagging tokens in it (n_chunks x 2)
+    // records pass, extended format: where the chunk stands inside its group
+    const uint32_t* chunk_o0;    // output bytes of the group in front of the chunk
+    const uint32_t* chunk_lag0;  // lag of the group in front of the chunk
+    const uint32_t* lagbase;     // index of the chunk's first entry in the lag lists
+    uint32_t* lag;               // lag lists, two words per lagging token (the split decoder's: Oend | Vend << 16, cumulative lag)
 };
 
 // 32 bits of the stream from bit position t, MSb first (bytes behind the end read as zero)
@@ -66,7 +87,7 @@ __device__ __forceinline__ uint32_t long_bits(const uint8_t* in, uint32_t n, uin
 // reference returns TAMP_INPUT_EXHAUSTED, decompressor.c:431-445); rec = the split decoder's record, or 0xFFFFFFFF for FLUSH
 // (no output), bad = an offset that runs out of the window (TAMP_OOB, :231-236,540-544).
 __device__ __forceinline__ uint32_t long_token(const uint8_t* in, uint32_t n, uint32_t t, const uint8_t* lut, uint32_t wbits,
-                                               uint32_t lbits, uint32_t minp, uint32_t& rec, bool& bad) {
+                                               uint32_t lbits, uint32_t minp, bool extended, uint32_t& rec, bool& bad) {
     const uint32_t avail = 8 * n - t;
     rec = 0xFFFFFFFFu;
     if (avail == 0) return 0;
@@ -83,6 +104,28 @@ __device__ __forceinline__ uint32_t long_token(const uint8_t* in, uint32_t n, ui
     const uint32_t used = coded ? 2 + (e0 >> 4) : 2u;
     if (avail < used) return 0;
     if (sym == (uint32_t)kSymFlush) return used + ((8 - ((t + used) & 7)) & 7);  // decompressor.c:501-514
+    if (extended && sym >= (uint32_t)kSymRle) {
+        // RLE: a second prefix code + 4 bits -> count - 2 (decompressor.c:114-174); extended match: code + 3 bits -> size - min - 12,
+        // then the window offset (:187-273).  How many bits the token takes depends on nothing but its own bits.
+        if (avail < used + 1) return 0;
+        const uint32_t w2 = long_bits(in, n, t + used);
+        const bool coded2 = (w2 >> 31) != 0;
+        const uint32_t e2 = lut[(w2 >> 24) & 0x7F];
+        const uint32_t h = coded2 ? (e2 & 15u) : 0u, trailing = sym == (uint32_t)kSymRle ? 4u : 3u;
+        uint32_t u = coded2 ? 1 + (e2 >> 4) : 1u;
+        if (avail < used + u + trailing) return 0;
+        const uint32_t value = (h << trailing) + ((w2 << u) >> (32 - trailing));
+        u += trailing;
+        if (sym == (uint32_t)kSymRle) {
+            rec = kRecFill | ((value + 2) << 2);
+            return used + u;
+        }
+        if (avail < used + u + wbits) return 0;
+        const uint32_t off = long_bits(in, n, t + used + u) >> (32 - wbits), len = value + minp + 12;
+        if (off + len > (1u << wbits)) bad = true;
+        rec = kRecCopyExt | (len << 2) | (off << 10);
+        return used + u + wbits;
+    }
     if (avail < used + wbits) return 0;
     const uint32_t off = (w << used) >> (32 - wbits), len = sym + minp;
     if (off + len > (1u << wbits)) bad = true;
@@ -116,7 +159,7 @@ __global__ void __launch_bounds__(64) tamp_long_sync_kernel(LongArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < a.n_chunks;
     const uint32_t minp = (uint32_t)min_pattern_size((int)a.wbits, (int)a.lbits);
-    const uint32_t end = (i + 1) * kLongChunkBits;
+    const uint32_t end = (i + 1) * a.chunk_bits;
     if (live) gs[threadIdx.x] = a.g[i];
     if (threadIdx.x == 63 || i + 1 == a.n_chunks) gs[threadIdx.x + 1] = live ? a.g[i + 1] : kLongEnd;
     __syncthreads();
@@ -130,7 +173,7 @@ __global__ void __launch_bounds__(64) tamp_long_sync_kernel(LongArgs a) {
             while (t != kLongEnd && t < end) {
                 uint32_t rec;
                 bool bad = false;
-                const uint32_t k = long_token(a.in, a.n, t, lut, a.wbits, a.lbits, minp, rec, bad);
+                const uint32_t k = long_token(a.in, a.n, t, lut, a.wbits, a.lbits, minp, a.extended != 0, rec, bad);
                 t = k ? t + k : kLongEnd;
             }
         }
@@ -149,34 +192,108 @@ __global__ void __launch_bounds__(64) tamp_long_sync_kernel(LongArgs a) {
     }
 }
 
-// The tokens that START in chunk i, from its settled start: counted (write = 0) or written as records (write = 1).
+// The tokens that START in chunk i, from its settled start: counted (write = 0), listed where they can lag (write = 2, extended
+// format), or written as records (write = 1).
 __global__ void __launch_bounds__(64) tamp_long_parse_kernel(LongArgs a) {
     __shared__ uint8_t lut[128];
     long_lut(lut);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_chunks) return;
     const uint32_t minp = (uint32_t)min_pattern_size((int)a.wbits, (int)a.lbits);
-    const uint32_t end = (i + 1) * kLongChunkBits, mask = (1u << a.wbits) - 1;
-    uint32_t t = a.g[i], nt = 0, nb = 0;
-    uint32_t* const out = a.write ? a.recs + a.tokbase[i] : nullptr;
-    const uint32_t rot = a.write ? a.rot[i] : 0u;
+    const uint32_t end = (i + 1) * a.chunk_bits, mask = (1u << a.wbits) - 1;
+    const bool ext = a.extended != 0;
+    uint32_t t = a.g[i], nt = 0, nb = 0, ns = 0;
+    uint32_t* const out = a.write == 1 ? a.recs + a.tokbase[i] : nullptr;
+    const uint32_t rot = a.write == 1 ? a.rot[i] : 0u;
+    // extended format: this chunk's entries of the special-token list (write = 2: filled in; write = 1: read back with what
+    // tamp_long_wp_kernel found), and where the chunk stands inside its group (write = 1)
+    uint32_t sb = 0, gap = 0, O = 0, cl = 0, li = 0;
+    if (ext && a.write) sb = a.specbase[i];
+    if (ext && a.write == 1) O = a.chunk_o0[i], cl = a.chunk_lag0[i], li = a.lagbase[i];
     bool bad = false;
     while (t != kLongEnd && t < end) {
         uint32_t rec;
-        const uint32_t k = long_token(a.in, a.n, t, lut, a.wbits, a.lbits, minp, rec, bad);
+        const uint32_t k = long_token(a.in, a.n, t, lut, a.wbits, a.lbits, minp, ext, rec, bad);
         if (!k) break;
         t += k;
         if (rec == 0xFFFFFFFFu) continue;  // FLUSH
-        if (a.write) {
-            // a group starts with its write cursor at window index `rot`: seen from there the offsets are (off - rot) mod W
-            if ((rec & 3u) == kRecCopy) rec = (rec & 0x3FFu) | ((((rec >> 10) - rot) & mask) << 10);
-            out[nt] = rec;
+        const uint32_t kind = rec & 3u, olen = (rec >> 2) & 0xFFu;
+        const bool special = kind == kRecFill || kind == kRecCopyExt;
+        if (a.write == 2) {
+            if (special) {
+                a.spec_gap[sb + ns] = gap, a.spec_kl[sb + ns] = olen | (kind == kRecFill ? 0x80000000u : 0u);
+                gap = 0;
+            } else {
+                gap += olen;
+            }
         }
+        if (a.write == 1) {
+            // a group starts with its write cursor at window index `rot`: seen from there the offsets are (off - rot) mod W
+            if (kind == kRecCopy || kind == kRecCopyExt) rec = (rec & 0x3FFu) | ((((rec >> 10) - rot) & mask) << 10);
+            out[nt] = rec;
+            O += olen;
+            if (special) {
+                const uint32_t wr = a.spec_written[sb + ns];
+                if (wr < olen) {  // a lag: the split decoder's list entry, positions counted from the group's start
+                    cl += olen - wr;
+                    a.lag[2 * li] = (O & 0xFFFFu) | (((O - cl) & 0xFFFFu) << 16);
+                    a.lag[2 * li + 1] = cl;
+                    li++;
+                }
+            }
+        }
+        if (special) ns++;
         nt++;
-        nb += (rec >> 2) & 0xFFu;
+        nb += olen;
     }
-    if (!a.write) a.ntok[i] = nt, a.outb[i] = nb;
+    if (a.write == 0) {
+        a.ntok[i] = nt, a.outb[i] = nb;
+        if (ext) a.nspec[i] = ns;
+    }
+    if (a.write == 2) a.spec_gap[sb + ns] = gap, a.spec_kl[sb + ns] = 0;  // the chunk's end marker
     if (bad) a.flags[1] = 1;
+}
+
+// Extended format: window_pos at every token that can lag.  An RLE token writes min(count, 8, W - window_pos) bytes to the window
+// and an extended match min(size, W - window_pos) (decompressor.c:162-170, 266-268: clipped at the ring's end, no wrap) -- the one
+// place where the token stream depends on the window, and only through the scalar window_pos: a chain over the RLE / extended-
+// match tokens (a few per cent of all tokens), with the byte counts of the plain tokens between them.  ONE workgroup: batches of
+// the list travel through LDS, one lane walks them.
+constexpr uint32_t kLongWpBatch = 4096;
+__global__ void __launch_bounds__(256) tamp_long_wp_kernel(LongArgs a, uint32_t n_entries) {
+    __shared__ uint32_t s_gap[kLongWpBatch], s_kl[kLongWpBatch], s_wr[kLongWpBatch];
+    __shared__ uint32_t s_state[4];
+    const uint32_t W = 1u << a.wbits, mask = W - 1;
+    if (threadIdx.x == 0) s_state[0] = 0, s_state[1] = 0, s_state[2] = 0, s_state[3] = 0;  // window_pos, cumulative lag, chunk, lags in the chunk
+    __syncthreads();
+    for (uint32_t base = 0; base < n_entries; base += kLongWpBatch) {
+        const uint32_t cnt = min(kLongWpBatch, n_entries - base);
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) s_gap[k] = a.spec_gap[base + k], s_kl[k] = a.spec_kl[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t wp = s_state[0], cum = s_state[1], chunk = s_state[2], nl = s_state[3];
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t kl = s_kl[k];
+                wp = (wp + s_gap[k]) & mask;
+                if (kl == 0) {  // the end of a chunk
+                    a.chunk_lag[2 * chunk] = cum, a.chunk_lag[2 * chunk + 1] = nl;
+                    chunk++, nl = 0;
+                    continue;
+                }
+                const uint32_t L = kl & 0xFFFFu;
+                const uint32_t room = W - wp;
+                uint32_t w = (kl >> 31) ? min(L, kRleWindowMax) : L;
+                w = min(w, room);
+                s_wr[k] = w;
+                if (w < L) cum += L - w, nl++;
+                wp = (wp + w) & mask;
+            }
+            s_state[0] = wp, s_state[1] = cum, s_state[2] = chunk, s_state[3] = nl;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) a.spec_written[base + k] = s_wr[k];
+        __syncthreads();
+    }
 }
 
 // The window in front of a group that starts inside the first W output bytes, oldest byte first: output so far, and the
@@ -215,7 +332,8 @@ __global__ void tamp_long_finish_kernel(uint32_t* out_len, int8_t* status, uint3
 // ---------------------------------------------------------------------------------------------------------------
 struct LongGroup {
     unsigned long long v0;  // output position of the group's first byte
-    uint32_t tok0, ntok, nout, pad;
+    uint32_t tok0, ntok, nout;
+    uint32_t lag0, nlag, pad;  // extended format: the group's entries of the lag lists (at most kLongMaxLag)
 };
 struct LongResolveArgs {
     const uint32_t* recs;
@@ -223,6 +341,9 @@ struct LongResolveArgs {
     uint8_t* out;            // the stream's output
     const uint8_t* dict0;    // the window of a fresh decoder (custom dictionary or the seeded default)
     uint16_t* tailmap;       // n_groups x W: byte k of the window behind group g = the byte itself, or kLongExt | j (see above)
+    const uint32_t* lag;     // extended format: lag lists (two words per lagging token, positions counted from the group's start)
+    uint8_t* groupwin;       // extended format: n_groups x W, the window in front of every group (the scan launch writes it, finish
+                             // reads it: with lags the window is no longer "the last W output bytes"); nullptr for v1
     uint32_t wbits;
     uint32_t n_groups;
 };
@@ -230,9 +351,9 @@ constexpr uint32_t kLongExt = 0x8000u;
 // output bytes per group of the one-launch resolve: twice RESOLVE's -- the groups' chain is serial, fewer and larger links are
 // faster (100 MB: 92 -> see DESIGN.md 4), and 96 KB of LDS still leaves a workgroup per CU waiting on every CU
 constexpr uint32_t kLongGroupOut = 32768;
-__host__ __device__ constexpr uint32_t long_resolve_lds() { return (kLongGroupOut + 16) + 2 * kLongGroupOut + 128; }
+__host__ __device__ constexpr uint32_t long_resolve_lds() { return (kLongGroupOut + 16) + 2 * kLongGroupOut + 128 + kLongMaxLag * 8; }
 
-template <int PHASE>  // 1 = tail maps, 2 = finish
+template <int PHASE, bool EXT>  // PHASE: 1 = tail maps, 2 = finish; EXT: RLE / extended-match records and lags (extended format)
 __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs ra) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t nt = 256, BPT = 4;
@@ -247,6 +368,31 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
     uint16_t* const src = reinterpret_cast<uint16_t*>(smem + capa + 16);
     typedef __attribute__((address_space(3))) volatile uint32_t LdsCtl;
     LdsCtl* const ctl = (LdsCtl*)(smem + capa + 16 + 2 * capa);
+    // Extended format: tokens that wrote fewer bytes to the window than they produced (tamp_decompress_split_kernel.hpp: every byte
+    // written to the window has a virtual position; output position = virtual position + the lag of the lagging tokens in front).
+    // The group's list, padded to kLongMaxLag entries that no position reaches: both look-ups are six-step binary searches.
+    uint32_t* const lagl = reinterpret_cast<uint32_t*>(smem + capa + 16 + 2 * capa + 128);
+    const uint32_t nlag = EXT ? gr.nlag : 0u;
+    if constexpr (EXT) {
+        for (uint32_t i = tid; i < kLongMaxLag; i += nt) {
+            lagl[2 * i] = i < nlag ? ra.lag[2 * (size_t)(gr.lag0 + i)] : 0xFFFFFFFFu;
+            lagl[2 * i + 1] = i < nlag ? ra.lag[2 * (size_t)(gr.lag0 + i) + 1] : 0u;
+        }
+    }
+    auto lag_before_out = [&](uint32_t O) -> uint32_t {  // lag of the lagging tokens that END at or before output position O
+        uint32_t idx = 0;
+#pragma unroll
+        for (uint32_t st = kLongMaxLag / 2; st; st >>= 1)
+            if ((lagl[2 * (idx + st - 1)] & 0xFFFFu) <= O) idx += st;
+        return idx ? lagl[2 * idx - 1] : 0u;
+    };
+    auto out_of_virtual = [&](uint32_t v) -> uint32_t {  // output position of the byte with virtual position v
+        uint32_t idx = 0;
+#pragma unroll
+        for (uint32_t st = kLongMaxLag / 2; st; st >>= 1)
+            if ((lagl[2 * (idx + st - 1)] >> 16) <= v) idx += st;
+        return v + (idx ? lagl[2 * idx - 1] : 0u);
+    };
     if (n_out) {
         for (uint32_t i = tid; i < capa / 2; i += nt) reinterpret_cast<uint32_t*>(src)[i] = 0;
         __syncthreads();
@@ -296,7 +442,7 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
                 const uint32_t pend = min(p0 + BPT, n_out);
                 if (head) {
                     const uint32_t r = rec[jcur];
-                    kind = r & 3u, arg = r >> 10, Vj = hpos;
+                    kind = r & 3u, arg = r >> 10, Vj = (EXT && nlag) ? hpos - lag_before_out(hpos) : hpos;
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < BPT; i++) {
@@ -306,13 +452,15 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
                     if (m) {
                         jcur = m - 1, hpos = p;
                         const uint32_t r = rec[jcur];
-                        kind = r & 3u, arg = r >> 10, Vj = hpos;
+                        kind = r & 3u, arg = r >> 10, Vj = (EXT && nlag) ? hpos - lag_before_out(hpos) : hpos;
                     }
                     const bool lit = kind == kRecLit;
-                    const uint32_t idx = (arg + (p - hpos)) & mask;  // (rotated) ring index read
+                    // (rotated) ring index read; an RLE token repeats the byte in front of it (decompressor.c:136-138)
+                    const uint32_t idx = (EXT && kind == kRecFill) ? ((Vj - 1) & mask) : ((arg + (p - hpos)) & mask);
                     const uint32_t back = (Vj - 1 - idx) & mask;      // 0 = newest ... W-1 = oldest
                     const bool ext = !lit && back >= Vj;              // not written by this group: the window in front of it
-                    const uint32_t v = Vj - 1 - back;
+                    uint32_t v = Vj - 1 - back;                       // virtual position inside the group ...
+                    if (EXT && nlag && !lit && !ext) v = out_of_virtual(v);  // ... and where that byte is in the output
                     src[p] = (uint16_t)(lit ? p : (ext ? (kLongExt | idx) : v));
                     outb[p] = (uint8_t)(lit ? arg : 0u);
                 }
@@ -369,15 +517,18 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
     if constexpr (PHASE == 1) {
         // the window as this group leaves it, oldest byte first: its own last bytes, and in front of them -- a group shorter
         // than W -- what is left of the window it found
+        // (extended format: the window holds what was WRITTEN -- the group's last W virtual positions)
         uint16_t* const tm = ra.tailmap + (size_t)g * W;
+        const uint32_t n_written = n_out - ((EXT && nlag) ? lagl[2 * nlag - 1] : 0u);
         for (uint32_t k = tid; k < W; k += nt) {
             uint32_t e;
-            if (n_out + k >= W) {
-                const uint32_t p = n_out + k - W;
+            if (n_written + k >= W) {
+                const uint32_t v = n_written + k - W;
+                const uint32_t p = (EXT && nlag) ? out_of_virtual(v) : v;
                 const uint32_t sp = src[p];
                 e = (sp & kLongExt) ? sp : (uint32_t)outb[p];
             } else {
-                e = kLongExt | (n_out + k);
+                e = kLongExt | (n_written + k);
             }
             tm[k] = (uint16_t)e;
         }
@@ -394,7 +545,9 @@ __global__ void __launch_bounds__(256) tamp_long_resolve_kernel(LongResolveArgs 
             if (sp & kLongExt) {
                 const uint32_t j = sp & 0x7FFFu;  // j-th oldest byte of the window in front of the group
                 uint32_t b;
-                if (v0 >= W) {
+                if (EXT) {
+                    b = ra.groupwin[(size_t)g * W + j];
+                } else if (v0 >= W) {
                     b = ra.out[v0 - W + j];
                 } else {
                     const uint32_t r = (j + wp0) & mask;
@@ -481,6 +634,10 @@ __global__ void __launch_bounds__(kLongScanThreads) tamp_long_tail_scan_kernel(L
         if constexpr (MODE == 1) {  // the window in front of block g
             for (uint32_t k = tid; k < W; k += nt) sa.blockwin[(size_t)g * W + k] = src[k];
         }
+        if constexpr (MODE == 2) {  // extended format: the window in front of group first + g, for the finish launch
+            if (ra.groupwin)
+                for (uint32_t k = tid; k < W; k += nt) ra.groupwin[(size_t)(first + g) * W + k] = src[k];
+        }
 #pragma unroll
         for (uint32_t i = 0; i < kPer; i++) {
             const uint32_t k = i * nt + tid;
@@ -492,7 +649,7 @@ __global__ void __launch_bounds__(kLongScanThreads) tamp_long_tail_scan_kernel(L
                     // window byte k is output byte vend - W + k -- when the stream is that old, and when this group wrote any of
                     // it (an empty group leaves the bytes where the group in front stored them)
                     const unsigned long long vend = s_vend[g];
-                    if (s_nout[g] && vend + k >= W) ra.out[vend + k - W] = (uint8_t)b;
+                    if (!ra.groupwin && s_nout[g] && vend + k >= W) ra.out[vend + k - W] = (uint8_t)b;
                 }
             }
         }

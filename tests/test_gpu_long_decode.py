@@ -87,6 +87,62 @@ def test_one_long_v1_stream_decodes_like_the_reference(ta, checker, name, conf, 
     assert int(r.status[0]) == 2 and bytes(r.stream(0)) == data
 
 
+EXT_CASES = [
+    ("prose_w10", dict(), "prose", 3_000_000),
+    ("python_w8", dict(window=8), "python", 1_500_000),      # runs of blanks: an RLE lag every few hundred bytes
+    ("python_w10", dict(), "python", 2_500_000),
+    ("python_w12", dict(window=12), "python", 1_500_000),
+    ("markup_w15", dict(window=15), "markup", 1_500_000),
+    ("prose_literal7", dict(literal=7), "prose7", 1_200_000),
+    ("prose_literal6", dict(literal=6), "prose6", 1_200_000),  # the seeded dictionary of 6-bit literals (decompressor.c:318-319)
+    ("zeros", dict(), "zeros", 40_000_000),         # nothing but 241-byte RLE tokens: more lags per chunk than a group lists
+    ("random", dict(), "random", 600_000),
+    ("period_1000", dict(), "period", 3_500_000),    # extended matches of 130+ bytes, clipped at the ring's end
+    ("runs_mixed", dict(), "runs", 2_000_000),       # runs of 2..300 bytes between words
+]
+
+
+@pytest.mark.parametrize("name,conf,kind,n", EXT_CASES, ids=[c[0] for c in EXT_CASES])
+def test_one_long_extended_stream_decodes_like_the_reference(ta, checker, name, conf, kind, n, monkeypatch):
+    """Round 6: the library's default format.  RLE / extended-match tokens write fewer bytes to the window than they produce
+    (decompressor.c:162-170,266-268); window_pos at those tokens comes from one pass over them (tamp_long_wp_kernel), the
+    groups' lag lists from there."""
+    if kind == "prose6":
+        data = bytes(b & 63 for b in _corpus("prose", n))
+    elif kind == "runs":
+        rng = np.random.default_rng(21)
+        words = _corpus("prose", 400_000).split()
+        parts, size = [], 0
+        while size < n:
+            w = words[int(rng.integers(len(words)))]
+            run = bytes([int(rng.integers(32, 127))]) * int(rng.integers(2, 300))
+            parts += [w, run]
+            size += len(w) + len(run)
+        data = b"".join(parts)[:n]
+    else:
+        data = _data(kind, n)
+    blob = ta.compress(data, **conf)  # extended = the default
+    assert blob[0] & 2
+    monkeypatch.setenv("TAMP_AMD_LONGDEC_MIN", "65536")  # (the long-stream decoder from 64 KiB of compressed bytes on)
+    assert len(blob) >= 64 << 10
+    st, out = _same_as_checker(ta, checker, blob, len(data) + 100)
+    assert st == 2 and out == data
+    assert bytes(ta.decompress(blob)) == data
+    # the exact decoders give the same answer (the path the launcher falls back to)
+    monkeypatch.setenv("TAMP_AMD_LONGDEC_EXT", "0")
+    r = ta.decompress_batch([blob], out_cap=len(data) + 100)
+    assert int(r.status[0]) == 2 and bytes(r.stream(0)) == data
+    monkeypatch.delenv("TAMP_AMD_LONGDEC_EXT")
+    # cut near the end and corrupted in the middle: whatever the reference makes of it
+    for cut in (1, 2, 3, 7):
+        _same_as_checker(ta, checker, blob[: len(blob) - cut], len(data) + 100)
+    rng = np.random.default_rng(6)
+    for _ in range(3):
+        bad = bytearray(blob)
+        bad[int(rng.integers(1000, len(bad)))] ^= 1 << int(rng.integers(8))
+        _same_as_checker(ta, checker, bytes(bad), len(data) + 4096)
+
+
 def test_long_stream_with_custom_dictionary_flush_tokens_and_a_tail(ta, checker):
     import io
 
