@@ -834,11 +834,13 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
         for (uint32_t i = 0; i < N; i++) specbase[i] = (uint32_t)n_entries, n_entries += (uint64_t)nspec[i] + 1;
         if (n_entries > 0xFFFFFFF0ull) { timing_end(st); return 1; }
         uint32_t* d_spec = nullptr;
+        const size_t n_wpblocks = (size_t)((n_entries + kLongWpBlock - 1) / kLongWpBlock);
         {
             std::lock_guard<std::mutex> lock(ctx->long_mu);
             DeviceCtx::HostPipe::Grow& sb = ctx->long_spec[st];
-            // gap, token, bytes written per list entry; behind them the lag lists (at most one entry per listed token)
-            if (sb.need((size_t)n_entries * (3 + 2) * 4 + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
+            // gap, token, bytes written per list entry; behind them the lag lists (at most one entry per listed token) and the
+            // window_pos tables of the list's blocks (tamp_long_wp_kernel: 8 bytes per block and start value, 20 per block)
+            if (sb.need((size_t)n_entries * (3 + 2) * 4 + n_wpblocks * ((size_t)W * 8 + 20) + 256) != hipSuccess) { (void)hipGetLastError(); timing_end(st); return 1; }
             d_spec = static_cast<uint32_t*>(sb.p);
         }
         la.specbase = d_specbase, la.spec_gap = d_spec, la.spec_kl = d_spec + n_entries, la.spec_written = d_spec + 2 * n_entries;
@@ -847,7 +849,18 @@ int launch_decompress_long(DeviceCtx* ctx, const uint8_t* d_dict, size_t dict_le
         HIP_OK(hipMemcpyAsync(d_specbase, specbase.data(), (size_t)N * 4, hipMemcpyHostToDevice, st));
         la.write = 2;
         hipLaunchKernelGGL(tamp_long_parse_kernel, dim3(lg), dim3(64), 0, st, la);
-        hipLaunchKernelGGL(tamp_long_wp_kernel, dim3(1), dim3(256), 0, st, la, (uint32_t)n_entries);
+        {
+            LongWpArgs wa;
+            wa.a = la, wa.n_entries = (uint32_t)n_entries, wa.n_blocks = (uint32_t)n_wpblocks;
+            wa.f_cum = d_spec + 5 * n_entries;
+            wa.markers = wa.f_cum + n_wpblocks * (size_t)W;
+            wa.state = wa.markers + n_wpblocks;
+            wa.f_wp = reinterpret_cast<uint16_t*>(wa.state + 4 * n_wpblocks);
+            wa.f_nl = wa.f_wp + n_wpblocks * (size_t)W;
+            hipLaunchKernelGGL(tamp_long_wp_kernel<0>, dim3((uint32_t)n_wpblocks), dim3(1024), 0, st, wa);
+            hipLaunchKernelGGL(tamp_long_wp_kernel<1>, dim3(1), dim3(64), 0, st, wa);
+            hipLaunchKernelGGL(tamp_long_wp_kernel<2>, dim3((uint32_t)n_wpblocks), dim3(256), 0, st, wa);
+        }
         chunk_lag.resize(2 * (size_t)N);
         HIP_OK(hipMemcpyAsync(chunk_lag.data(), d_chunk_lag, 2 * (size_t)N * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));  // (also: specbase goes out of scope)

@@ -257,42 +257,84 @@ __global__ void __launch_bounds__(64) tamp_long_parse_kernel(LongArgs a) {
 // Extended format: window_pos at every token that can lag.  An RLE token writes min(count, 8, W - window_pos) bytes to the window
 // and an extended match min(size, W - window_pos) (decompressor.c:162-170, 266-268: clipped at the ring's end, no wrap) -- the one
 // place where the token stream depends on the window, and only through the scalar window_pos: a chain over the RLE / extended-
-// match tokens (a few per cent of all tokens), with the byte counts of the plain tokens between them.  ONE workgroup: batches of
-// the list travel through LDS, one lane walks them.
-constexpr uint32_t kLongWpBatch = 4096;
-__global__ void __launch_bounds__(256) tamp_long_wp_kernel(LongArgs a, uint32_t n_entries) {
-    __shared__ uint32_t s_gap[kLongWpBatch], s_kl[kLongWpBatch], s_wr[kLongWpBatch];
-    __shared__ uint32_t s_state[4];
+// match tokens (a few per cent of all tokens), with the byte counts of the plain tokens between them.  One lane walking the whole
+// list took 167 ms for a 100 MB stream (560 cycles an entry: dependent LDS reads in a lone wavefront); the chain is cut into blocks
+// of kLongWpBlock entries instead:
+//   MODE 0  a workgroup per block runs the block from EVERY possible window_pos at once (a thread per start value: W of them, the
+//           entries broadcast from LDS): where window_pos ends up, the lag added, the lagging tokens behind the block's last chunk
+//           marker -- three tables of W entries per block;
+//   MODE 1  one lane walks the blocks' tables (a look-up per block): the state in front of every block;
+//   MODE 2  a lane per block walks its entries from that state and writes what every token wrote and the chunks' totals.
+constexpr uint32_t kLongWpBlock = 2048;
+struct LongWpArgs {
+    LongArgs a;
+    uint32_t n_entries, n_blocks;
+    uint16_t* f_wp;        // n_blocks x W: window_pos behind the block, by window_pos in front of it
+    uint32_t* f_cum;       // ... lag the block adds
+    uint16_t* f_nl;        // ... lagging tokens behind its last chunk marker (the whole block's when it has none)
+    uint32_t* markers;     // n_blocks: chunk markers in the block
+    uint32_t* state;       // n_blocks x 4: window_pos, lag, chunk, lagging tokens of the open chunk -- in front of the block
+};
+template <int MODE>
+__global__ void __launch_bounds__(1024) tamp_long_wp_kernel(LongWpArgs x) {
+    const LongArgs& a = x.a;
+    __shared__ uint32_t s_gap[kLongWpBlock], s_kl[kLongWpBlock], s_wr[MODE == 2 ? kLongWpBlock : 1];
     const uint32_t W = 1u << a.wbits, mask = W - 1;
-    if (threadIdx.x == 0) s_state[0] = 0, s_state[1] = 0, s_state[2] = 0, s_state[3] = 0;  // window_pos, cumulative lag, chunk, lags in the chunk
-    __syncthreads();
-    for (uint32_t base = 0; base < n_entries; base += kLongWpBatch) {
-        const uint32_t cnt = min(kLongWpBatch, n_entries - base);
+    if constexpr (MODE == 1) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            uint32_t wp = 0, cum = 0, chunk = 0, nl = 0;
+            for (uint32_t b = 0; b < x.n_blocks; b++) {
+                x.state[4 * b] = wp, x.state[4 * b + 1] = cum, x.state[4 * b + 2] = chunk, x.state[4 * b + 3] = nl;
+                const size_t at = (size_t)b * W + wp;
+                const uint32_t m = x.markers[b], tail = x.f_nl[at];
+                cum += x.f_cum[at];
+                nl = m ? tail : nl + tail;
+                chunk += m;
+                wp = x.f_wp[at];
+            }
+        }
+        return;
+    } else {
+        const uint32_t base = blockIdx.x * kLongWpBlock;
+        const uint32_t cnt = min(kLongWpBlock, x.n_entries - base);
         for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) s_gap[k] = a.spec_gap[base + k], s_kl[k] = a.spec_kl[base + k];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t wp = s_state[0], cum = s_state[1], chunk = s_state[2], nl = s_state[3];
+        auto run = [&](uint32_t wp, uint32_t cum, uint32_t chunk, uint32_t nl, uint32_t& wp_out, uint32_t& cum_out, uint32_t& nl_out,
+                       uint32_t& nmark) {
+            nmark = 0;
             for (uint32_t k = 0; k < cnt; k++) {
                 const uint32_t kl = s_kl[k];
                 wp = (wp + s_gap[k]) & mask;
                 if (kl == 0) {  // the end of a chunk
-                    a.chunk_lag[2 * chunk] = cum, a.chunk_lag[2 * chunk + 1] = nl;
-                    chunk++, nl = 0;
+                    if constexpr (MODE == 2) a.chunk_lag[2 * (size_t)chunk] = cum, a.chunk_lag[2 * (size_t)chunk + 1] = nl;
+                    chunk++, nl = 0, nmark++;
                     continue;
                 }
                 const uint32_t L = kl & 0xFFFFu;
-                const uint32_t room = W - wp;
                 uint32_t w = (kl >> 31) ? min(L, kRleWindowMax) : L;
-                w = min(w, room);
-                s_wr[k] = w;
+                w = min(w, W - wp);
+                if constexpr (MODE == 2) s_wr[k] = w;
                 if (w < L) cum += L - w, nl++;
                 wp = (wp + w) & mask;
             }
-            s_state[0] = wp, s_state[1] = cum, s_state[2] = chunk, s_state[3] = nl;
+            wp_out = wp, cum_out = cum, nl_out = nl;
+        };
+        if constexpr (MODE == 0) {
+            for (uint32_t wp_in = threadIdx.x; wp_in < W; wp_in += blockDim.x) {
+                uint32_t wp, cum, nl, nm;
+                run(wp_in, 0, 0, 0, wp, cum, nl, nm);
+                const size_t at = (size_t)blockIdx.x * W + wp_in;
+                x.f_wp[at] = (uint16_t)wp, x.f_cum[at] = cum, x.f_nl[at] = (uint16_t)nl;
+                if (wp_in == 0) x.markers[blockIdx.x] = nm;
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                uint32_t wp, cum, nl, nm;
+                run(x.state[4 * blockIdx.x], x.state[4 * blockIdx.x + 1], x.state[4 * blockIdx.x + 2], x.state[4 * blockIdx.x + 3], wp, cum, nl, nm);
+            }
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) a.spec_written[base + k] = s_wr[k];
         }
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) a.spec_written[base + k] = s_wr[k];
-        __syncthreads();
     }
 }
 
