@@ -1077,6 +1077,20 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 TAMP_REPEAT(0x10000u) {
                     const uint8_t* src = in + e_p0;
                     const uint32_t nfill = align_up(nload + 20, 4);  // zero tail: stray look-ahead reads are defined
+#ifndef TAMP_LOAD_BYTES
+                    {
+                        // whole dwords wherever the block starts in the stream (global loads need no alignment on gfx950): behind a
+                        // lag the block starts at an odd position three times out of four, and a byte at a time this was six
+                        // dependent round trips to HBM per epoch -- 156 us of the 1.1 ms the slowest chunk of the stand-in takes alone
+                        const uint32_t nw = nload >> 2;
+                        for (uint32_t k = tid; k < nw; k += nt) {
+                            uint32_t v;
+                            __builtin_memcpy(&v, src + 4 * k, 4);
+                            reinterpret_cast<uint32_t*>(ebuf + W)[k] = v;
+                        }
+                        for (uint32_t k = (nw << 2) + tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
+                    }
+#else
                     if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
                         const uint32_t nw = nload >> 2;
                         for (uint32_t k = tid; k < nw; k += nt)
@@ -1085,6 +1099,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     } else {
                         for (uint32_t k = tid; k < nfill; k += nt) ebuf[W + k] = k < nload ? src[k] : 0;
                     }
+#endif
                 }
                 for (uint32_t k = tid; k < kBuckets / 2; k += nt) cntw[k] = 0;
                 if (tid == 0) ctl[cCut] = 0xFFFFFFFFu;
