@@ -851,14 +851,17 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
     static_assert(HB >= 9 && HB <= 11, "entry payload: 16 - HB bigram bits + 8 bits of the third byte + the rest of the fourth");
     constexpr uint32_t kRem = 16 - HB, kBuckets = 1u << HB;
-    // Round 6, the W = 2^10 build of the default parse: index entries laid out for ONE subtraction + ONE compare per candidate,
-    //     rest of the bigram (5 bits) << 27 | buffer position (12 bits) << 15 | third byte | low 7 bits of the fourth << 8
-    // With x = entry ^ (the query's rest << 27 | its own bytes 2, 3) and y = x - (q << 15):  y < (W - 1) << 15  <=>  same
-    // bigram AND 0 <= position - q <= W - 2 (a position in front of the window borrows into the rest field; a foreign rest
-    // leaves at least 2^27 - (q << 15) >= 3073 << 15, q <= 1,024).  y >> 15 is the distance from the oldest window byte, the low
-    // 15 bits classify 2- / 3-byte candidates and the ones worth a compare -- where the 16 + 11 + 5 layout spent a masked
-    // subtraction, a three-way bit operation, two compares and a scalar AND.
-    constexpr bool kEntV2 = PACKED && !LAZY && WSCAN == 1024 && HB == 11;
+    // Round 6, default parse with u32 entries: index entries laid out for ONE subtraction + ONE compare per candidate,
+    //     rest of the bigram (kRem bits) << (kPB + kLB) | buffer position (kPB bits) << kLB | third byte | low bits of the fourth << 8
+    // With x = entry ^ (the query's rest << (kPB + kLB) | its own bytes 2, 3) and y = x - (q << kLB):  y < (W - 1) << kLB  <=>
+    // same bigram AND 0 <= position - q <= W - 2 (a position in front of the window borrows into the rest field; a foreign rest
+    // leaves at least (2^kPB - q) << kLB, and 2^kPB - q >= W - 1 for every block a build runs).  y >> kLB is the distance from the
+    // oldest window byte, the low kLB bits classify 2- / 3-byte candidates and the ones worth a compare -- where the 16 + 11 + 5
+    // layout spent a masked subtraction, a three-way bit operation, two compares and a scalar AND.  The W = 2^10 build holds its
+    // positions (below 2,352) in 12 bits and keeps 7 bits of the fourth byte; the others 16 and 3 (512 buckets: 1).
+    constexpr bool kEntV2 = PACKED && !LAZY;
+    constexpr uint32_t kPB = WSCAN == 1024 ? 12u : 16u, kLB = 32u - kRem - kPB;
+    static_assert(!kEntV2 || kLB >= 9, "the third byte and at least one bit of the fourth");
     static_assert(!(RUNS && LAZY), "the run list serves the default parse only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // LOOP builds: this workgroup's claim on the work counter (next stream, end of the claim, the stream in hand, start of
@@ -1255,7 +1258,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         if (keep) {
                             const uint32_t old = atomicAdd(&cntw[h >> 1], 1u << sh);
                             if (kEntV2)
-                                ent[(old >> sh) & 0xFFFFu] = ((mx & ((1u << kRem) - 1)) << 27) | (c << 15) | ((b4 >> 16) & 0x7FFFu);
+                                ent[(old >> sh) & 0xFFFFu] = ((mx & ((1u << kRem) - 1)) << (kPB + kLB)) | (c << kLB) | ((b4 >> 16) & ((1u << kLB) - 1));
                             else if (PACKED)
                                 ent[(old >> sh) & 0xFFFFu] = c | entry_payload<kRem>(b4, mx);
                             else
@@ -1341,7 +1344,17 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // Skipping the scan there removes the worst buckets.
                     const uint32_t rep = (P[0] & 0xFFu) * 0x01010101u;
                     bool in_run = false;
-                    if (ext && !lazy && ebuf[W + q - 1] == (P[0] & 0xFFu)) {
+#ifndef TAMP_SETUP_R5
+                    // (round 6: the byte in front of the pattern is read ONCE -- it is also the newest window byte of the wrap-zone
+                    // test and the byte the slow flag looks at -- and the run arithmetic runs only where the pattern starts with
+                    // TWO of it: with one, r <= 1 < the shortest pattern and nothing below applies, and some lane of nearly every
+                    // wavefront had one)
+                    const uint32_t prevb = ebuf[W + q - 1];
+                    if (ext && !lazy && (P[0] & 0xFFFFu) == prevb * 0x0101u) {
+#else
+                    const uint32_t prevb = ebuf[W + q - 1];
+                    if (ext && !lazy && prevb == (P[0] & 0xFFu)) {
+#endif
                         // r = leading ring bytes equal to the previous byte, looked at up to 7
                         const uint32_t x0 = P[0] ^ rep, x1 = (P[1] ^ rep) & 0x00FFFFFFu;
                         const uint32_t r = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : (x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : 7u);
@@ -1363,9 +1376,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         uint32_t e_next = PACKED ? ent[sl] : (uint32_t)ent16[sl];  // software prefetch of the next entry
                         TAMP_FINE(f0);
                         if constexpr (kEntV2) {
-                            constexpr uint32_t Ws = WSCAN;
-                            const uint32_t pkx = ((mix16(P[0] & 0xFFFFu) & ((1u << kRem) - 1)) << 27) | ((P[0] >> 16) & 0x7FFFu);
-                            const uint32_t qs = q << 15;
+                            const uint32_t Ws = WSCAN ? WSCAN : W;  // (see the template parameter)
+                            const uint32_t pkx = ((mix16(P[0] & 0xFFFFu) & ((1u << kRem) - 1)) << (kPB + kLB)) | ((P[0] >> 16) & ((1u << kLB) - 1));
+                            const uint32_t qs = q << kLB;
                             const uint32_t nb = ~(q + e_wp);  // W - window index of the candidate at distance d = ((nb - d) & (W - 1)) + 1
                             const uint32_t* pe = ent + sl;
                             const uint32_t* const pe_end = ent + s_hi;
@@ -1383,9 +1396,9 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                 pe++;
                                 e_next = *pe;  // one past the range at the end: harmless
                                 const uint32_t y = (e ^ pkx) - qs;
-                                if (y < ((Ws - 1) << 15)) {  // in the window and the same bigram
-                                    const uint32_t d = y >> 15;  // Ws - d bytes before the candidate reaches the newest byte
-                                    const uint32_t low = y & 0x7FFFu;
+                                if (y < ((Ws - 1) << kLB)) {  // in the window and the same bigram
+                                    const uint32_t d = y >> kLB;  // Ws - d bytes before the candidate reaches the newest byte
+                                    const uint32_t low = y & ((1u << kLB) - 1);
                                     uint32_t len = (low & 0xFFu) ? 2u : 3u;
 #ifdef TAMP_PROF
                                     if (low == 0 && !(a.dbg & 0x8000u)) {
@@ -1396,7 +1409,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                                         }
                                     } else if (low == 0) len = 4u;
 #else
-                                    if (low == 0) len = prefix_len16(ebuf, q + d, P);  // the next two bytes agree too (7 bits of the second)
+                                    if (low == 0) len = prefix_len16(ebuf, q + d, P);  // the next two bytes agree too (the entry's bits of the second)
 #endif
                                     // (the wrap zone and the key: as in the generic loop below.  One test: the compare reaches the
                                     // newest byte iff d + len >= Ws; a 16-byte hit exactly 16 bytes in front of it -- exact as it
@@ -1519,7 +1532,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         // with the OLDEST byte; t = 1 (the newest byte itself) pairs with the oldest one and is therefore
                         // not in the index at all: test its first byte here.
                         // (a match there needs the oldest byte to equal the pattern's second byte as well)
-                        if (ebuf[q + W - 1] == (P[0] & 0xFFu) && ebuf[q] == ((P[0] >> 8) & 0xFFu)) wrapmask |= 2u;
+                        if (prevb == (P[0] & 0xFFu) && ebuf[q] == ((P[0] >> 8) & 0xFFu)) wrapmask |= 2u;
 #ifdef TAMP_PROF
                         const uint32_t wrapmask0 = wrapmask;
                         for (uint32_t rep = 0; rep < ((a.dbg & 0x200u) ? 2u : 1u); rep++) {
@@ -1586,7 +1599,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // tested there and only the byte condition is recorded here)
                     bool slow = false;
                     if (ext) {
-                        const uint32_t prev = ebuf[W + q - 1], b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
+                        const uint32_t prev = prevb, b0 = P[0] & 0xFFu, b1 = (P[0] >> 8) & 0xFFu;
                         slow = (prev == b0 && (b1 == b0 || R == 1)) || (!lazy && len > minp + 11);
                     }
                     // kSegPartial: no parse step without a full ring -- the chain of plain steps stops where the call ends
