@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_TAG = "r5"     # profiles/<tag>_pmc_{fetch,write,sq,sq2}_counter_collection.csv feed roofline.traffic / valu_*
+PROFILE_TAG = "r6"     # profiles/<tag>_pmc_{fetch,write,sq,sq2}_counter_collection.csv feed roofline.traffic / valu_*
 
 
 class Shard:

@@ -37,8 +37,10 @@ copy("dec2_stats_kernel_stats.csv", f"{rnd}_decode_variants_kernel_stats.csv")
 copy("dec_split_kernel_stats.csv", f"{rnd}_decode_split_kernel_stats.csv")
 counters("dec_split_sq_counter_collection.csv", f"{rnd}_pmc_decode_split_sq_counter_collection.csv")
 copy("realtext_stats_kernel_stats.csv", f"{rnd}_realtext_kernel_stats.csv")
+copy("longdec_v1_kernel_stats.csv", f"{rnd}_long_decode_v1_kernel_stats.csv")
+copy("longdec_ext_kernel_stats.csv", f"{rnd}_long_decode_extended_kernel_stats.csv")
 with open(os.path.join(dst, f"{rnd}_decode_and_realtext_rates.txt"), "w") as fh:
-    for f in ("dec4_stats.log", "dec2_stats.log", "realtext_stats.log", "config5.log", "short_msgs.log", "dec_split_pmc.log",
+    for f in ("longdec_v1.log", "longdec_ext.log", "dec4_stats.log", "dec2_stats.log", "realtext_stats.log", "config5.log", "short_msgs.log", "dec_split_pmc.log",
               "realtext_prose_sq.log", "realtext_markup_sq.log", "realtext_python_sq.log", "dec2_fetch.log"):
         p = os.path.join(src, f)
         if os.path.exists(p):

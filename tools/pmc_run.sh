@@ -3,7 +3,7 @@
 # do not fit into one pass).  Summaries land in gpurun_out/pmc_$TAG; copy what is to be tracked into profiles/.
 #   usage (GPU box, repo root): TAG=r2a bash tools/pmc_run.sh
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-TAG=${TAG:-r4}
+TAG=${TAG:-r6}
 OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 # ---- compress kernel (configs[1], the bench command) ----
@@ -38,6 +38,9 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT -o c5_sq -- pytho
 # ---- decode of the bench batch (65,536 x 4 KiB, split decoder): HBM traffic ----
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o dec2_fetch -- python tools/dec_traffic.py > $OUT/dec2_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o dec2_write -- python tools/dec_traffic.py > $OUT/dec2_write.log 2>&1
+# ---- ONE long stream decoded by the whole device (round 6): v1 and the extended format ----
+EXT=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o longdec_v1 -- python tools/long_dec_prof.py > $OUT/longdec_v1.log 2>&1
+EXT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o longdec_ext -- python tools/long_dec_prof.py > $OUT/longdec_ext.log 2>&1
 ls $OUT
 cat $OUT/bench.json
 python - <<PY
@@ -52,4 +55,4 @@ for f in sorted(glob.glob('$OUT/*_kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         if 'tamp' in r['Name']: print(f.split('/')[-1], r['Name'][:70], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
 PY
-grep -h "GB/s\|per stream" $OUT/dec4_stats.log $OUT/dec2_stats.log $OUT/realtext_stats.log $OUT/config5.log $OUT/short_msgs.log $OUT/dec_split_pmc.log
+grep -h "GB/s\|per stream" $OUT/longdec_v1.log $OUT/longdec_ext.log $OUT/dec4_stats.log $OUT/dec2_stats.log $OUT/realtext_stats.log $OUT/config5.log $OUT/short_msgs.log $OUT/dec_split_pmc.log
