@@ -117,6 +117,16 @@ def compress_batch(data, in_off=None, in_len=None, *, window: int = 10, literal:
     ``reuse`` (device batches with an integer ``out_cap``): the result of an earlier call with the same stream count and
     capacity on the same device; its output slab and tables are overwritten instead of allocating new ones.
     """
+    if stream is not None and _is_torch(data):
+        # The call makes its tables (capacities, offsets) and its output slab with torch: they have to come into being on the
+        # stream the kernels are enqueued on, or the launch races the fill kernels of torch's current stream (and the caching
+        # allocator hands the slab's memory on while the launch still writes it).
+        import torch
+
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=data.device)):
+            return compress_batch(data, in_off, in_len, window=window, literal=literal, extended=extended, dictionary=dictionary,
+                                  dictionary_reset=dictionary_reset, lazy_matching=lazy_matching, out_cap=out_cap,
+                                  max_in_len=max_in_len, device=device, stream=None, timing=timing, run_aware=run_aware, reuse=reuse)
     lib = _lib.load()
     conf = _conf(window, literal, extended, dictionary, dictionary_reset, lazy_matching, run_aware)
     if dictionary is not None and not _is_torch(dictionary) and len(dictionary) != (1 << window):
@@ -208,6 +218,12 @@ def decompress_batch(data, in_off=None, in_len=None, *, out_cap, dictionary=None
     2 (INPUT_EXHAUSTED) on normal completion, 1 (OUTPUT_FULL) if ``out_cap[i]`` was reached with work left,
     -4 / -3 for malformed input.
     """
+    if stream is not None and _is_torch(data):
+        import torch  # (tables and output slab on the launch stream: see compress_batch)
+
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=data.device)):
+            return decompress_batch(data, in_off, in_len, out_cap=out_cap, dictionary=dictionary, max_window_bits=max_window_bits,
+                                    scan_headers=scan_headers, device=device, stream=None, timing=timing)
     lib = _lib.load()
     lib.tamp_amd_set_timing(1 if timing else 0)
     if not scan_headers:
