@@ -1857,25 +1857,32 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         // (profiles/ab/r4_listing_step_table.log; two tokens per round trip on top: no further gain).
                         if (b + lane < nv) xcnt[b + lane] = (uint8_t)stepv;
                     }
-                    // packed: target * 4 (relative target 0..97 as the byte offset ds_bpermute wants) | count << 10 |
-                    // finished << 18.  A round is five VALU operations: the count field of the own state is added onto
-                    // the state fetched from the target (which brings target, count and the finished bit along; counts
-                    // stay below 256, nothing carries), finished lanes keep theirs.
-                    constexpr uint32_t kFin = 1u << 18, kCnt = (0xFFu << 10) | (BLOCKM ? 0xFFF80000u : 0u);
-                    uint32_t st = slowp ? (((uint32_t)lane << 2) | kFin) : ((((uint32_t)lane + stepv) << 2) | (1u << 10));
+                    // packed: target * 4 (the byte offset ds_bpermute wants) | count << 10 (| bits << 19 in block mode).  Round 6:
+                    // a chain ENDS on a lane -- a slow position, or one whose step leaves the block -- and such a lane points at
+                    // itself with a count of zero, so a round is a fixed point for it and needs no "finished" select: fetch the
+                    // target's state, add the own count onto it (three VALU operations and the bpermute where there were six).
+                    // What the end lane contributes -- its exit target and its own token, or itself and nothing -- is fetched
+                    // once behind the six rounds.
+                    constexpr uint32_t kCnt = (0xFFu << 10) | (BLOCKM ? 0xFFF80000u : 0u);
+                    const uint32_t tgt = (uint32_t)lane + stepv;
+                    const bool endp = slowp || tgt >= 64u;
+                    uint32_t own = 1u << 10;  // this position's token: one, and in block mode its bits
                     if constexpr (BLOCKM) {
-                        // block mode: the bits of the chain's tokens ride along in bits 19.. (a 64-position block's tokens
-                        // take 64 x 9 + 24 bits at most: literal 1 + 8, match prefix code + window bits per two positions or more)
+                        // (a 64-position block's tokens take 64 x 9 + 24 bits at most: literal 1 + 8, match prefix code + window bits
+                        // per two positions or more)
                         const uint32_t lenv = sv & 0x1Fu;
-                        const uint32_t tb = lenv >= minp ? tok_nbits(lenv - minp) + wbits : lbits + 1u;
-                        if (!slowp) st |= tb << 19;
+                        own |= (lenv >= minp ? tok_nbits(lenv - minp) + wbits : lbits + 1u) << 19;
                     }
-                    if ((st & 0x3FFu) >= 256u) st |= kFin;
+                    uint32_t st = endp ? ((uint32_t)lane << 2) : ((tgt << 2) | own);
+                    const uint32_t endv = slowp ? ((uint32_t)lane << 2) : ((tgt << 2) | own);  // (read only from end lanes)
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
                         const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(st & 0x3FFu), (int)st);
-                        const uint32_t nw = o2 + (st & kCnt);
-                        st = (st & kFin) ? st : nw;
+                        st = o2 + (st & kCnt);
+                    }
+                    {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(st & 0x3FFu), (int)endv);
+                        st = e + (st & kCnt);
                     }
                     if constexpr (BLOCKM) {
                         if (a.block_pass == 1 && b + lane < nv) toklist[b + lane] = (uint16_t)(st >> 19);  // (pass 1 lists no tokens: the space is free)

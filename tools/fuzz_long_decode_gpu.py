@@ -1,4 +1,4 @@
-"""Randomised v1 streams through the long-stream decoder (tamp_decompress_long_kernel.hpp; TAMP_AMD_LONGDEC_MIN lowered so that
+"""Randomised streams of both formats (EXT_P = share of extended ones, default 0.5) through the long-stream decoder (tamp_decompress_long_kernel.hpp; TAMP_AMD_LONGDEC_MIN lowered so that
 streams of a few hundred bytes take it too) against the oracle's decoder: bytes, status, consumed count -- windows 8..15,
 literal bits 5..8, custom dictionaries, FLUSH tokens, truncated and corrupted streams, output room from too small to ample.
 usage: python tools/fuzz_long_decode_gpu.py [seconds]   (GPU box)"""
@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
         ops.append(("write", x[pos:pos + k])); pos += k
         if rng.random() < 0.3: ops.append(("flush", rng.random() < 0.7))
     ops.append(("close",))
-    st, blob = oracle.stream_script(ops, window=w, literal=lit, extended=rng.random() < 0.1, dictionary=dic)
+    st, blob = oracle.stream_script(ops, window=w, literal=lit, extended=rng.random() < float(os.environ.get('EXT_P', '0.5')), dictionary=dic)
     assert st == 0
     u = rng.random()
     if u < 0.2 and len(blob) > 3: blob = blob[:rng.randrange(1, len(blob))]
