@@ -1625,20 +1625,8 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #else
                     if (nruns) {
 #endif
-#ifndef TAMP_PASS2_SORTED
-                        // (round 6: the queries in their NATURAL order here -- a wavefront's 64 queries are 64 consecutive positions,
-                        // so a listed run that lies outside all their windows is skipped by the whole wavefront at once, and the
-                        // positions inside one indented line are active together: Python sources 22 k -> 13 k VALU in this pass.
-                        // Another thread may have written a query's first-pass result: a barrier in front)
-                        __syncthreads();
-                        for (uint32_t j = tid; j < nq; j += nt) {
-                            const uint32_t q = e_pending + j;
-                            const uint32_t q_lo = Walk::uni(q - (uint32_t)lane);  // the wavefront's first query
-#else
                         for (uint32_t j = tid; j < nq; j += nt) {
                             const uint32_t q = sorted[j];
-                            const uint32_t q_lo = 0;
-#endif
                             const uint32_t b01 = lds_u32_unaligned(ebuf, W + q);
                             const uint32_t x = b01 & 0xFFu;
                             if (((b01 >> 8) & 0xFFu) != x) continue;
@@ -1707,10 +1695,6 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             for (uint32_t k = 0; k < nruns; k++) {
                                 const uint32_t rv = Walk::uni(runs[k]), rx = Walk::uni(runsx[k]);
                                 const uint32_t ra = rv & 0xFFFFu, rb = rv >> 16;
-#ifndef TAMP_PASS2_SORTED
-                                // (interior candidates are ra+1 .. rb-4; the wavefront's windows reach from q_lo to q_lo + 63 + W - 16)
-                                if (rb < q_lo + 4 || ra + 1 > q_lo + 63 + W - 16) continue;
-#endif
                                 const uint32_t lo = max(ra + 1, q), hi = min(rb - 4, qhi);
                                 if ((rx & 0xFFu) != x || lo > hi) continue;
                                 const int32_t cs = (int32_t)rb - (int32_t)rq;
