@@ -1507,7 +1507,10 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
         const HostSlot s = slot_of(j, ch);
         const size_t cnt = ch.i1 - ch.i0;
         hipStream_t st = P.s[j];
-        if (ch.out_packed && ch.out_hi > ch.out_lo)
+        // (a handful of streams -- ONE long stream decoded with room for its worst case: tamp.decompress(100 MB) offers 325 MB --
+        // first learn what was produced and copy exactly that: the packed path below would move the whole extent)
+        const bool out_packed = ch.out_packed && cnt > 16;
+        if (out_packed && ch.out_hi > ch.out_lo)
             HIP_OK(hipMemcpyAsync(b.out + ch.out_lo, P.out[j].p, ch.out_hi - ch.out_lo, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(b.out_len + ch.i0, s.out_len, cnt * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(b.status + ch.i0, s.status, cnt, hipMemcpyDeviceToHost, st));
@@ -1516,11 +1519,14 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
         // (staging pays when the extent is mostly produced bytes; a sparse or permuted batch can span gigabytes for a few
         // megabytes of output -- those, and extents above 512 MiB of pinned memory per slot, take the merged copies below)
         size_t produced = 0;
-        if (!ch.out_packed)
+        if (!out_packed)
             for (size_t i = ch.i0; i < ch.i1; i++) produced += b.out_len[i];
         const size_t extent = ch.out_hi - ch.out_lo;
-        const bool stage_ok = extent <= ((size_t)512 << 20) && extent <= 8 * produced + ((size_t)1 << 20);
-        if (!ch.out_packed && ch.out_hi > ch.out_lo && stage_ok && !getenv("TAMP_AMD_NO_STAGED_COPYBACK") &&
+        // (... and a handful of streams with room to spare -- one long stream decoded into 8 x its compressed size -- copy their
+        // produced bytes directly: the extent of tamp.decompress(100 MB) is 325 MB for 100 MB of output)
+        const bool stage_ok = extent <= ((size_t)512 << 20) && extent <= 8 * produced + ((size_t)1 << 20) &&
+                              (cnt > 16 || extent <= produced + produced / 4 + ((size_t)1 << 20));
+        if (!out_packed && ch.out_hi > ch.out_lo && stage_ok && !getenv("TAMP_AMD_NO_STAGED_COPYBACK") &&
             P.stage[j].need(ch.out_hi - ch.out_lo) == hipSuccess) {
             // One device-to-pinned transfer of the chunk's whole extent, then exactly the produced bytes of every stream
             // placed by the host: bytes between and behind the slabs are never written.  (One hipMemcpyAsync per stream,
@@ -1530,7 +1536,7 @@ int run_host_batch(DeviceCtx* ctx, int device, const HostBatch& b, const std::ve
             HIP_OK(hipStreamSynchronize(st));
             for (size_t i = ch.i0; i < ch.i1; i++)
                 if (b.out_len[i]) memcpy(b.out + b.out_off[i], stg + (b.out_off[i] - ch.out_lo), b.out_len[i]);
-        } else if (!ch.out_packed) {
+        } else if (!out_packed) {
             (void)hipGetLastError();  // (a failed pinned allocation must not poison later calls)
             // exactly the produced bytes of every stream, runs of touching full slabs merged into one transfer
             const uint8_t* dev_out = static_cast<const uint8_t*>(P.out[j].p);
