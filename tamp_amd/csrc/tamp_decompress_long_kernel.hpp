@@ -1,5 +1,5 @@
-// tamp_decompress_long_kernel.hpp -- ONE long v1 stream decoded by the whole device (round 5; the decode side of block mode,
-// tamp_compress_kernel.hpp BLOCKM).
+// tamp_decompress_long_kernel.hpp -- ONE long stream decoded by the whole device (v1: round 5, the decode side of block mode,
+// tamp_compress_kernel.hpp BLOCKM; the extended format: round 6).
 //
 // Replaces, for one stream, tamp_decompressor_decompress (tamp/_c_src/tamp/decompressor.c:371-578) where its token loop is
 // position-independent: the v1 format without a dictionary reset -- a literal is 1 + literal bits, a match is the flag, a
@@ -20,8 +20,13 @@
 //      (TAMP_AMD_LONGDEC_CHAIN=0: groups of kSplitMaxOut bytes through the split decoder's RESOLVE, one launch after the
 //      other, each with the W output bytes in front of it as its "dictionary".)
 //
-// Anything else -- extended format, dictionary reset, an out-of-bounds offset, an output buffer that is too small, a sync
-// that does not settle -- is left to the exact decoders: the launcher falls back before anything has been written.
+// The extended format (round 6) adds RLE / extended-match tokens, which write fewer bytes to the window than they produce
+// (decompressor.c:162-170, 266-268): window_pos at those tokens comes from tamp_long_wp_kernel, the groups get the split decoder's
+// lag lists.  Scalar model of steps 3 and of the window_pos pass: tests/test_host_logic.py
+// (test_long_stream_groups_tail_maps_and_window_pos_blocks_model).
+// Anything else -- dictionary reset, an out-of-bounds offset, an output buffer that is too small, a sync that does not settle,
+// more lagging tokens in one chunk than a group lists -- is left to the exact decoders: the launcher falls back before anything
+// has been written.
 #pragma once
 #include "tamp_common.hpp"
 #include "tamp_decompress_split_kernel.hpp"

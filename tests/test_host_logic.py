@@ -519,3 +519,140 @@ def test_long_stream_chunk_starts_settle_on_the_token_boundaries(oracle):
         assert all(x is None or x in bounds for x in g[:-1]), name  # every settled start is a true token boundary
         if name in ("text", "runs"):
             assert rounds <= 4, (name, rounds)
+
+
+def test_long_stream_groups_tail_maps_and_window_pos_blocks_model():
+    """Round 6, the long-stream decoder's step 3 restated on the CPU (tamp_decompress_long_kernel.hpp): a token stream is cut
+    into groups; every group is resolved ALONE -- a byte whose source lies in front of the group stays "byte j of the window in
+    front" -- and leaves a tail map; the maps compose into the window in front of every group; a second pass fills in the
+    externals.  With RLE / extended-match tokens (decompressor.c:114-273: fewer bytes written to the window than produced,
+    clipped at the ring's end) window_pos comes from a pass over those tokens in blocks: every block from every start value,
+    one look-up per block.  Checked against a plain sequential decoder, random token streams, small windows."""
+    import random
+
+    def sequential(tokens, W, dic):
+        win, wp, out = list(dic), 0, []
+        for t in tokens:
+            if t[0] == "lit":
+                src, wr = [t[1]], 1
+            elif t[0] == "copy":
+                src = [win[t[1] + i] for i in range(t[2])]
+                wr = t[2]
+            elif t[0] == "rle":
+                src = [win[(wp - 1) % W]] * t[1]
+                wr = min(t[1], 8, W - wp)
+            else:  # ext
+                src = [win[t[1] + i] for i in range(t[2])]
+                wr = min(t[2], W - wp)
+            out += src
+            for b in src[:wr]:
+                win[wp] = b
+                wp = (wp + 1) % W
+        return out
+
+    def window_pos_in_blocks(tokens, W, block):
+        """bytes every token writes to the window: tamp_long_wp_kernel's three modes"""
+        specials = [(i, t) for i, t in enumerate(tokens) if t[0] in ("rle", "ext")]
+        entries, last = [], 0  # (gap of plain bytes in front, kind, produced)
+        plain = [0]
+        for t in tokens:
+            plain.append(plain[-1] + ((1 if t[0] == "lit" else t[2]) if t[0] in ("lit", "copy") else 0))
+        for i, t in specials:
+            entries.append((plain[i] - plain[last], t[0], t[1] if t[0] == "rle" else t[2]))
+            last = i + 1
+
+        def run(wp, ents, written=None):
+            for gap, kind, L in ents:
+                wp = (wp + gap) % W
+                w = min(min(L, 8) if kind == "rle" else L, W - wp)
+                if written is not None:
+                    written.append(w)
+                wp = (wp + w) % W
+            return wp
+
+        blocks = [entries[i:i + block] for i in range(0, len(entries), block)]
+        tables = [[run(wp, b) for wp in range(W)] for b in blocks]  # MODE 0
+        starts, wp = [], 0
+        for tab in tables:  # MODE 1
+            starts.append(wp)
+            wp = tab[wp]
+        written = []
+        for b, s in zip(blocks, starts):  # MODE 2
+            run(s, b, written)
+        return {i: w for (i, _), w in zip(specials, written)}
+
+    def grouped(tokens, W, dic, group_out, wp_block):
+        written = window_pos_in_blocks(tokens, W, wp_block)
+        # groups of whole tokens
+        groups, cur, size = [], [], 0
+        for i, t in enumerate(tokens):
+            n = 1 if t[0] == "lit" else (t[1] if t[0] == "rle" else t[2])
+            if cur and size + n > group_out:
+                groups.append(cur)
+                cur, size = [], 0
+            cur.append(i)
+            size += n
+        groups.append(cur)
+        V = 0  # bytes written to the window in front of the group
+        resolved, maps = [], []
+        for g in groups:
+            rot = V % W
+            out, virt = [], []  # per output byte: ("b", byte) / ("o", output position in the group) / ("x", j); virtual -> output position
+            for i in g:
+                t = tokens[i]
+                Vj = len(virt)
+                if t[0] == "lit":
+                    src, wr = [("b", t[1])], 1
+                else:
+                    n = t[1] if t[0] == "rle" else t[2]
+                    src = []
+                    for k in range(n):
+                        idx = (Vj - 1) % W if t[0] == "rle" else (t[1] - rot + k) % W  # rotated ring index read
+                        back = (Vj - 1 - idx) % W
+                        src.append(("x", idx) if back >= Vj else ("o", virt[Vj - 1 - back]))
+                    wr = n if t[0] == "copy" else written[i]
+                base = len(out)
+                out += src
+                virt += [base + k for k in range(wr)]
+            # pointers resolved inside the group
+            for p in range(len(out)):
+                while out[p][0] == "o":
+                    out[p] = out[out[p][1]]
+            n_written = len(virt)
+            tail = []
+            for k in range(W):
+                v = n_written + k - W
+                tail.append(out[virt[v]] if v >= 0 else ("x", n_written + k))
+            resolved.append(out)
+            maps.append(tail)
+            V += n_written
+        # the window in front of every group: the maps composed from the fresh decoder's window
+        win, fronts = list(dic), []
+        for m in maps:
+            fronts.append(win)
+            win = [e[1] if e[0] == "b" else win[e[1]] for e in m]
+        res = []
+        for out, front in zip(resolved, fronts):
+            res += [e[1] if e[0] == "b" else front[e[1]] for e in out]
+        return res
+
+    rng = random.Random(6)
+    for W in (16, 32, 64):
+        for trial in range(60):
+            dic = [rng.randrange(256) for _ in range(W)]
+            tokens = []
+            for _ in range(rng.randrange(1, 400)):
+                u = rng.random()
+                if u < 0.45:
+                    tokens.append(("lit", rng.randrange(256)))
+                elif u < 0.75:
+                    n = rng.randrange(2, min(W, 16))
+                    tokens.append(("copy", rng.randrange(0, W - n + 1), n))
+                elif u < 0.9:
+                    tokens.append(("rle", rng.randrange(2, 40)))
+                else:
+                    n = rng.randrange(2, W)
+                    tokens.append(("ext", rng.randrange(0, W - n + 1), n))
+            want = sequential(tokens, W, dic)
+            for group_out, wp_block in ((37, 5), (150, 64), (10**9, 10**9)):
+                assert grouped(tokens, W, dic, group_out, wp_block) == want, (W, trial, group_out)
