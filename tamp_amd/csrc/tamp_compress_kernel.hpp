@@ -1161,6 +1161,10 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         if (c4 + j < NE0) {
                             const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRem;
                             atomicAdd(&cntw[h >> 1], 1u << ((h & 1) * 16));
+                            // (round 6: a block position's bucket stays in its `qstart` slot until the scatter turns it into the
+                            // cursor snapshot -- the bigram was loaded and hashed a second time there)
+                            if (c4 >= W) qstart[c4 + j - W] = (uint16_t)h;
+#endif
                         }
                     }
                 }
@@ -1241,8 +1245,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 // Two cursor snapshots bracket what a query must scan: the cursor of its bucket when the tile holding
                 // its oldest window byte starts (qstart) and after the tile holding its own position (top, in bidx).
                 if (tid < nvalid) {
-                    const uint32_t b4 = lds_u32_unaligned(ebuf, W + tid);
-                    qstart[tid] = cnt16[mix16(b4 & 0xFFFFu) >> kRem];  // queries of tile 0: bucket start
+                    qstart[tid] = cnt16[qstart[tid]];  // queries of tile 0: bucket start (the slot held the bucket's number)
                 }
                 __syncthreads();
                 for (uint32_t t0 = 0; t0 < NE; t0 += nt) {
@@ -1269,8 +1272,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     if (c < NE && c >= W) bidx[c - W] = cnt16[h];
                     const uint32_t q2 = t0 + nt + tid;  // queries whose oldest window byte lies in the next tile
                     if (q2 < nvalid) {
-                        const uint32_t b4 = lds_u32_unaligned(ebuf, W + q2);
-                        qstart[q2] = cnt16[mix16(b4 & 0xFFFFu) >> kRem];
+                        qstart[q2] = cnt16[qstart[q2]];
                     }
                     __syncthreads();
                 }
@@ -1302,7 +1304,6 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     __syncthreads();
                     goto index_again;
                 }
-#endif
                 TAMP_PROF_MARK(1);
 
                 // ---------------- match: find_best_match for every position of the block ----------------
