@@ -1164,7 +1164,6 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                             // (round 6: a block position's bucket stays in its `qstart` slot until the scatter turns it into the
                             // cursor snapshot -- the bigram was loaded and hashed a second time there)
                             if (c4 >= W) qstart[c4 + j - W] = (uint16_t)h;
-#endif
                         }
                     }
                 }
@@ -1244,9 +1243,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                 // Tile-ordered scatter.  After tile t every bucket lists the positions of tiles 0..t in tile order.
                 // Two cursor snapshots bracket what a query must scan: the cursor of its bucket when the tile holding
                 // its oldest window byte starts (qstart) and after the tile holding its own position (top, in bidx).
-                if (tid < nvalid) {
-                    qstart[tid] = cnt16[qstart[tid]];  // queries of tile 0: bucket start (the slot held the bucket's number)
-                }
+                if (tid < nvalid) qstart[tid] = cnt16[qstart[tid]];  // queries of tile 0: bucket start (the slot held the bucket's number)
                 __syncthreads();
                 for (uint32_t t0 = 0; t0 < NE; t0 += nt) {
                     const uint32_t c = t0 + tid;
@@ -1271,9 +1268,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     __syncthreads();
                     if (c < NE && c >= W) bidx[c - W] = cnt16[h];
                     const uint32_t q2 = t0 + nt + tid;  // queries whose oldest window byte lies in the next tile
-                    if (q2 < nvalid) {
-                        qstart[q2] = cnt16[qstart[q2]];
-                    }
+                    if (q2 < nvalid) qstart[q2] = cnt16[qstart[q2]];
                     __syncthreads();
                 }
                 // Order the queries by scan length (counting sort, longest first) so that the 64 lanes of a wave
@@ -1304,6 +1299,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     __syncthreads();
                     goto index_again;
                 }
+#endif
                 TAMP_PROF_MARK(1);
 
                 // ---------------- match: find_best_match for every position of the block ----------------
