@@ -219,15 +219,16 @@ struct SegmentSpec {  // streaming Compressor over the engine: how this piece of
     uint8_t flags;  // kSegResume | kSegSave | kSegFlushToken
 };
 
-uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, bool runlist = false) {
+uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, bool runlist = false, uint32_t hb = kHashBits) {
     // Positions matched per epoch (a multiple of 64: the walk chases 64 positions per register; of 256 when it can be:
     // the index is scattered in tiles of 256 positions, two barriers each, and a last tile that is mostly empty costs
     // as much as a full one).  The whole stream when it is short.  For longer ones what counts is how many workgroups a
     // CU holds -- the kernel is bound by instruction issue and a third of a real-text stream's time is the one-wavefront
     // walk -- so: the LARGEST block that still allows as many workgroups per CU as a 1,024-position block does (the
-    // registers allow TAMP_WG_PER_CU = 7 for the run-aware builds, 6 for the lean and 5 for the lazy ones).  At W = 1024
-    // that is 1,024 positions at seven per CU (21.4 KB; rounds 1-3: 1,536 at six, 26.3 KB): four epochs instead of three
-    // for a 4 KiB stream, and still faster on every input measured (profiles/ab/r4_seven_workgroups_per_cu.log).
+    // registers allow TAMP_WG_PER_CU = 8 for the run-aware builds since round 6, 6 for the lean and 5 for the lazy ones).  At
+    // W = 1024 that is 1,024 positions at eight per CU (19.2 KB with 1,024 buckets; round 4-5: seven at 21.4 KB; rounds 1-3: 1,536
+    // positions at six, 26.3 KB): four epochs instead of three for a 4 KiB stream, and faster on every input measured
+    // (profiles/ab/r4_seven_workgroups_per_cu.log, profiles/ab/r6_experiments.log).
     uint32_t blk = max_in_len ? align_up(max_in_len, 64) : 2048;
     if (blk > 2048) blk = 2048;
     if (blk > 1024) {
@@ -235,7 +236,7 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
         const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
         const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
         auto per_cu = [&](uint32_t b) {
-            const uint32_t v = lds_cu / align_up(CompressLds(W, b, packed, lazy, runlist).total, granule);
+            const uint32_t v = lds_cu / align_up(CompressLds(W, b, packed, lazy, runlist, hb).total, granule);
             return v < reg_cap ? v : reg_cap;
         };
         const uint32_t want = per_cu(1024);
@@ -424,12 +425,13 @@ int launch_compress_blocks(DeviceCtx* ctx, CompressArgs a0, const TampAmdConf* c
         n_max = std::max(n_max, in_len[i]);
     }
     const bool runs_build = !getenv("TAMP_AMD_BLOCK_LEAN");  // (the run-aware build, as for every long stream; tuning: the lean one)
-    a0.blk = pick_block(W, 0, true, false, runs_build);
+    const uint32_t hb = runs_build && conf->window == 10 ? kHb1024 : kHashBits;
+    a0.blk = pick_block(W, 0, true, false, runs_build, hb);
     if (a0.blk > 1024) a0.blk = 1024;  // (more, smaller blocks: the unit of parallelism here)
-    const CompressLds L(W, a0.blk, true, false, runs_build);
+    const CompressLds L(W, a0.blk, true, false, runs_build, hb);
     if (L.total > ctx->lds_per_block) return 1;
     auto kernel = !runs_build ? tamp_compress_kernel<true, false, false, 0, kHashBits, true, true>
-                  : conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHashBits, true, true>
+                  : conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHb1024, true, true>
                                        : tamp_compress_kernel<true, false, true, 0, kHashBits, true, true>;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
     int per_cu = 0;
@@ -537,12 +539,13 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     const bool long_streams = max_in_len == 0 || align_up(max_in_len, 64) >= 1024;  // (= 256-thread workgroups, pick_block)
     bool runlist = packed && !a.lazy && (long_streams || conf->input_hint == TAMP_AMD_HINT_RUNS);
     if (const char* e = getenv("TAMP_AMD_RUNS")) { if (!long_streams) runlist = packed && !a.lazy && atoi(e) != 0; }  // tuning / tests
-    a.blk = pick_block(W, max_in_len, packed, a.lazy != 0, runlist);
-    if (runlist && CompressLds(W, a.blk, packed, false, true).total > ctx->lds_per_block) {
-        snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", CompressLds(W, a.blk, packed, false, true).total, ctx->lds_per_block);
+    const uint32_t hb = runlist && conf->window == 10 ? kHb1024 : kHashBits;
+    a.blk = pick_block(W, max_in_len, packed, a.lazy != 0, runlist, hb);
+    if (runlist && CompressLds(W, a.blk, packed, false, true, hb).total > ctx->lds_per_block) {
+        snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", CompressLds(W, a.blk, packed, false, true, hb).total, ctx->lds_per_block);
         return TAMP_AMD_BAD_ARGUMENT;  // (cannot happen for windows up to 2^14: 105 KB at most)
     }
-    const CompressLds L(W, a.blk, packed, a.lazy != 0, runlist);
+    const CompressLds L(W, a.blk, packed, a.lazy != 0, runlist, hb);
     if (L.total > ctx->lds_per_block) {
         snprintf(t_last_error, sizeof t_last_error, "LDS %u B > %zu B per block", L.total, ctx->lds_per_block);
         return TAMP_AMD_BAD_ARGUMENT;
@@ -562,7 +565,7 @@ int launch_compress(DeviceCtx* ctx, const TampAmdConf* conf, const uint8_t* d_di
     const bool short_build = packed && !a.lazy && !runlist;
     auto kernel = a.lazy ? (packed ? tamp_compress_kernel<true, true, false, 0, kHashBits, true> : tamp_compress_kernel<false, true, false, 0, kHashBits, true>)
                   : !packed ? tamp_compress_kernel<false, false, false, 0, kHashBits, true>
-                  : runlist ? (conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHashBits, true> : tamp_compress_kernel<true, false, true, 0, kHashBits, true>)
+                  : runlist ? (conf->window == 10 ? tamp_compress_kernel<true, false, true, 1024, kHb1024, true> : tamp_compress_kernel<true, false, true, 0, kHashBits, true>)
                             : tamp_compress_kernel<true, false, false, 0, 9>;
     if (short_build && threads != 64) {  // (short messages only: long streams are run-aware above)
         snprintf(t_last_error, sizeof t_last_error, "no lean build for %u-thread workgroups", threads);

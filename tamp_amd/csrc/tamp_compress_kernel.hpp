@@ -53,7 +53,17 @@ constexpr int kPrioScan = 0, kPrioShort = 2, kPrioWalk = 3;
 constexpr uint32_t kDeferMin = TAMP_DEFER_MIN;
 constexpr uint32_t kDeferred = 0x1Fu;  // length field of blen: no real first match is longer than the 16-byte ring
 constexpr uint32_t kLongRun = TAMP_LONG_RUN;    // a run of one byte this long is listed; its interior leaves the bigram index
-constexpr uint32_t kSlowCap = 256;             // explicit (non-derivable) token pieces per walk segment
+// Round 6, late: EIGHT workgroups per CU for the W = 2^10 run-aware build.  The round's loop fits 64 VGPRs without a spill, and
+// 1,024 buckets (2 KB of cursors instead of 4; a foreign entry costs six instructions since the one-compare layout) with 128
+// explicit pieces per walk segment bring the workgroup to 19,616 B of LDS: synthetic 5.31 -> 4.97 ms, prose / markup / Python
+// sources -6 % each (profiles/ab/r6_experiments.log).  TAMP_SEVEN restores the round's earlier shape for A/B runs.
+#ifdef TAMP_SEVEN
+#define TAMP_WG_PER_CU 7
+constexpr uint32_t kSlowCap = 256, kHb1024 = kHashBits;
+#else
+constexpr uint32_t kSlowCap = 128;             // explicit (non-derivable) token pieces per walk segment
+constexpr uint32_t kHb1024 = 10;               // bucket bits of the W = 2^10 run-aware build
+#endif
 
 struct CompressArgs {
     const uint8_t* in;
@@ -94,12 +104,12 @@ struct CompressArgs {
 struct CompressLds {
     uint32_t ebuf, cnt, ent, blen, bidx, blen2, bidx2, obuf, ctl, runs, runsx, rxset, rbits, total;  // blen2/bidx2: lazy-matching probe results
     uint32_t tokcap, obuf_words, jump, count, vstep;  // jump/count/vstep: byte offsets of the walk's tables inside `ent`
-    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false, bool runlist = false) {
+    __host__ __device__ CompressLds(uint32_t W, uint32_t blk, bool packed, bool lazy = false, bool runlist = false, uint32_t hb = kHashBits) {
         uint32_t o = 16;  // slack: the wrapped compare reads up to 15 bytes in front of ebuf (masked out)
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
         cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
-        o += kHashBuckets * 2;
+        o += (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;  // (512-bucket builds keep the full region: the walk needs it)
         tokcap = blk + kPendMax + kRing + 80;
         // lazy matching walks (position, state) pairs: two table slots per position and the transitions themselves
         const uint32_t vblk = lazy ? 2 * blk : blk;
@@ -755,7 +765,7 @@ struct Walk {
 // real text, whose workgroups spend a third of their time in the one-wavefront walk, gains 8-10 % from the seventh
 // (profiles/ab/r4_seven_workgroups_per_cu.log).  Eight (64 VGPRs) spills 92 registers.
 #ifndef TAMP_WG_PER_CU
-#define TAMP_WG_PER_CU 7
+#define TAMP_WG_PER_CU 8
 #endif
 // Block size after a break (a token that wrote fewer bytes than it consumed threw the rest of the block away): with the
 // 1,536-position blocks of rounds 1-3 halving it (512 at least) was worth 15 % on real text; with 1,024-position blocks
@@ -908,7 +918,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
         const uint32_t a_wbits = a.wbits, a_blk = a.blk;
         const uint32_t W = 1u << a_wbits, mask = W - 1;
         constexpr bool lazy = LAZY;
-        const CompressLds L(W, a_blk, PACKED, lazy, RUNS);
+        const CompressLds L(W, a_blk, PACKED, lazy, RUNS, HB == 9 ? kHashBits : HB);
         uint8_t* const ebuf = smem + L.ebuf;
         uint16_t* const cnt16 = reinterpret_cast<uint16_t*>(smem + L.cnt);
         uint32_t* const cntw = reinterpret_cast<uint32_t*>(smem + L.cnt);
@@ -1750,7 +1760,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     // jump tables chase and the emitter turns into bits, unless the window write would be clipped at the
                     // ring end (W - window_pos bytes, :355 / :404-410): those, long runs, runs reaching the end of the
                     // input and matches with rivals stay with the state machine.
-                    if (ext && (kSlowCap * 8 + a_blk) <= kHashBuckets * 2) {
+                    if (ext && (kSlowCap * 8 + a_blk) <= (HB == 9 ? kHashBuckets : kBuckets) * 2) {
                         const uint32_t max_ext = minp + 11 + kExtExtraMax;
 #ifdef TAMP_PROF
                         // (0x4000000: a dry run in front -- everything but the stores -- for the pass's instruction count)
