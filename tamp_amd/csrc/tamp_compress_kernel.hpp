@@ -187,7 +187,14 @@ __device__ __forceinline__ uint32_t tok_nbits(uint32_t i) { return (uint32_t)(kN
 #define TAMP_MIX_MUL 46437u
 #endif
 static_assert((TAMP_MIX_MUL & 1u) == 1u && TAMP_MIX_MUL < 65536u, "odd 16-bit multiplier: a bijection on bigrams");
-__device__ __forceinline__ uint32_t mix16(uint32_t pair16) { return (pair16 * TAMP_MIX_MUL) & 0xFFFFu; }
+// (1,024 buckets -- the W = 2^10 build since the end of round 6 -- have their own best multiplier: tools/hash_search.py with HB=10
+// scans 7.53 entries per query of the synthetic text with 5455 where 46437 scans 8.03; prose 11.19 / 11.54, markup 10.72 / 11.30)
+#ifndef TAMP_MIX_MUL10
+#define TAMP_MIX_MUL10 5455u
+#endif
+static_assert((TAMP_MIX_MUL10 & 1u) == 1u && TAMP_MIX_MUL10 < 65536u, "odd 16-bit multiplier: a bijection on bigrams");
+template <uint32_t HBITS = kHashBits>
+__device__ __forceinline__ uint32_t mix16(uint32_t pair16) { return (pair16 * (HBITS == 10 ? TAMP_MIX_MUL10 : TAMP_MIX_MUL)) & 0xFFFFu; }
 // entry payload from 4 little-endian bytes b0..b3 at a position: rem | b2 | low bits of b3, in bits 16..31
 template <uint32_t REM = kRemBits>
 __device__ __forceinline__ uint32_t entry_payload(uint32_t bytes4, uint32_t mix) {
@@ -1169,7 +1176,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
                         if (c4 + j < NE0) {
-                            const uint32_t h = mix16(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRem;
+                            const uint32_t h = mix16<HB>(__builtin_amdgcn_alignbyte(d1, d0, j) & 0xFFFFu) >> kRem;
                             atomicAdd(&cntw[h >> 1], 1u << ((h & 1) * 16));
                             // (round 6: a block position's bucket stays in its `qstart` slot until the scatter turns it into the
                             // cursor snapshot -- the bigram was loaded and hashed a second time there)
@@ -1260,7 +1267,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     uint32_t h = 0;
                     if (c < NE) {
                         const uint32_t b4 = lds_u32_unaligned(ebuf, c);
-                        const uint32_t mx = mix16(b4 & 0xFFFFu);
+                        const uint32_t mx = mix16<HB>(b4 & 0xFFFFu);
                         h = mx >> kRem;
                         const uint32_t sh = (h & 1) * 16;
                         bool keep = true;
@@ -1376,7 +1383,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                     if (R >= minp && !in_run) {
 #endif
                         const uint32_t cap_len = R < maxp ? R : maxp;
-                        const uint32_t pk = entry_payload<kRem>(P[0], mix16(P[0] & 0xFFFFu));
+                        const uint32_t pk = entry_payload<kRem>(P[0], mix16<HB>(P[0] & 0xFFFFu));
                         const uint32_t chi = q + W - 2;  // newest candidate served by the index
                         const uint32_t s_hi = bidx[q];
                         uint32_t sl = qstart[q], wrapmask = 0;
@@ -1384,7 +1391,7 @@ __global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) t
                         TAMP_FINE(f0);
                         if constexpr (kEntV2) {
                             const uint32_t Ws = WSCAN ? WSCAN : W;  // (see the template parameter)
-                            const uint32_t pkx = ((mix16(P[0] & 0xFFFFu) & ((1u << kRem) - 1)) << (kPB + kLB)) | ((P[0] >> 16) & ((1u << kLB) - 1));
+                            const uint32_t pkx = ((mix16<HB>(P[0] & 0xFFFFu) & ((1u << kRem) - 1)) << (kPB + kLB)) | ((P[0] >> 16) & ((1u << kLB) - 1));
                             const uint32_t qs = q << kLB;
                             const uint32_t nb = ~(q + e_wp);  // W - window index of the candidate at distance d = ((nb - d) & (W - 1)) + 1
                             const uint32_t* pe = ent + sl;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side search for the 16-bit multiplier of the bigram mix (tamp_compress_kernel.hpp: mix16).  The index keys its
-2,048 buckets by the top 11 bits of (bigram * M) mod 2^16 -- any odd M is a bijection, so exactness does not depend on it,
+buckets by the top HB bits of (bigram * M) mod 2^16 (2,048 until round 6, 1,024 for the W = 2^10 build since) -- any odd M is a bijection, so exactness does not depend on it,
 only how many foreign bigrams share a query's bucket.  For every candidate M this replays the kernel's brackets (tile-ordered
 buckets, 256-position tiles) on epoch buffers cut from the synthetic text and the frozen corpora and reports
 entries scanned per query and lock-step iterations per 64 queries after the sort by bracket length.
@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tamp_amd  # noqa: E402
 from tamp_amd import workloads as wl  # noqa: E402
 
-W, BLK, TILE, HB = 1024, 1536, 256, 11
+W, TILE = 1024, 256
+BLK, HB = int(os.environ.get('BLK', '1024')), int(os.environ.get('HB', '10'))  # (round 6: 1,024 positions, 1,024 buckets)
+CUR = int(os.environ.get('CUR', '46437'))
 DICT = np.frombuffer(bytes(tamp_amd.initialize_dictionary(W)), dtype=np.uint8)
 
 
@@ -22,7 +24,7 @@ def epochs(rows):
     out = []
     for r in rows:
         hist = np.concatenate([DICT, r]).astype(np.uint32)
-        for e0 in (0, 1536, 3072):
+        for e0 in range(0, len(r), BLK):
             nv = min(BLK, len(r) - e0)
             buf = hist[e0:e0 + W + nv + 1]
             if len(buf) < W + nv + 1:
@@ -60,13 +62,14 @@ def main():
         "synth": wl.synth_text(24, 4096),
         "prose": wl.tile_rows(wl.real_text("prose"), 768)[::19][:24],
         "python": wl.tile_rows(wl.real_text("python"), 768)[::19][:24],
+        "markup": wl.tile_rows(wl.real_text("markup"), 768)[::19][:24],
     }
     eps = {k: epochs(v) for k, v in corp.items()}
-    base = {k: cost(v, 40503) for k, v in eps.items()}
-    print("current M=40503:", {k: (round(a, 2), round(b, 2)) for k, (a, b) in base.items()})
+    base = {k: cost(v, CUR) for k, v in eps.items()}
+    print(f"current M={CUR} (HB={HB}, BLK={BLK}):", {k: (round(a, 2), round(b, 2)) for k, (a, b) in base.items()})
     # coarse pass: every odd multiplier on a few epochs per corpus
     small = {k: v[:ncoarse] for k, v in eps.items()}
-    b0 = {k: cost(v, 40503)[1] for k, v in small.items()}
+    b0 = {k: cost(v, CUR)[1] for k, v in small.items()}
     res = []
     for M in range(1, 65536, 2):
         sc = 0.0
