@@ -1747,8 +1747,9 @@ int tamp_amd_compress_plan(uint8_t window_bits, uint32_t max_in_len, int lazy_ma
     const bool packed = window_bits <= 14, lazy = lazy_matching != 0;
     const bool long_streams = max_in_len == 0 || align_up(max_in_len, 64) >= 1024;
     const bool runlist = packed && !lazy && long_streams;
-    const uint32_t blk = pick_block(W, max_in_len, packed, lazy, runlist);
-    const CompressLds L(W, blk, packed, lazy, runlist);
+    const uint32_t hb = runlist && window_bits == 10 ? kHb1024 : kHashBits;
+    const uint32_t blk = pick_block(W, max_in_len, packed, lazy, runlist, hb);
+    const CompressLds L(W, blk, packed, lazy, runlist, hb);
     const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
     const uint32_t by_lds = 160u * 1024u / align_up(L.total, 2048u);
     if (block_positions) *block_positions = blk;

@@ -50,16 +50,17 @@ def test_host_helpers_need_no_device(oracle):
         for lit in range(5, 9):
             assert lib.tamp_compute_min_pattern_size(w, lit) == oracle.min_pattern_size(w, lit)
     assert lib.tamp_amd_compress_bound(4096, 8, 0) == 4609
-    # the compress launch plan (round 4: seven workgroups per CU for the run-aware builds, the largest block that allows it)
+    # the compress launch plan (round 6: EIGHT workgroups per CU for the run-aware builds -- 64 VGPRs, 1,024 buckets at window 2^10 --
+    # and the largest block that allows it)
     def plan(w, n, lazy=0):
         v = [ctypes.c_uint32(0) for _ in range(4)]
         assert lib.tamp_amd_compress_plan(w, n, lazy, *[ctypes.byref(x) for x in v]) == 0
         return tuple(x.value for x in v)
     blk, lds, threads, per_cu = plan(10, 4096)
-    assert (blk, threads, per_cu) == (1024, 256, 7) and lds <= 22528
+    assert (blk, threads, per_cu) == (1024, 256, 8) and lds <= 20480
     assert plan(10, 0)[0] == 1024 and plan(10, 1 << 20)[0] == 1024
     assert plan(10, 256)[:1] == (256,) and plan(10, 256)[2] == 64          # short messages: one wavefront, the whole message
-    assert plan(8, 4096)[0] % 256 == 0 and plan(8, 4096)[3] == 7            # smaller windows: the same (1,280 positions miss the seventh workgroup by 64 bytes)
+    assert plan(8, 4096)[0] % 256 == 0 and plan(8, 4096)[3] == 8            # smaller windows: the same
     assert plan(11, 4096)[3] == plan(11, 1024)[3] and plan(11, 4096)[0] >= 1024   # larger windows: the largest block at the occupancy of a 1,024-position one
     for w in range(8, 16):
         b, l, t, c = plan(w, 4096)
