@@ -234,7 +234,7 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     if (blk > 1024) {
         // (LDS is handed out in coarse granules: 26,960 B per workgroup measured as five per CU, 25,424 B as six)
         const uint32_t lds_cu = 160u * 1024u, granule = 2048u;
-        const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
+        const uint32_t reg_cap = lazy ? (uint32_t)TAMP_LAZY_PER_CU : (runlist ? (uint32_t)TAMP_WG_PER_CU : (uint32_t)TAMP_LEAN_PER_CU);
         auto per_cu = [&](uint32_t b) {
             const uint32_t v = lds_cu / align_up(CompressLds(W, b, packed, lazy, runlist, hb).total, granule);
             return v < reg_cap ? v : reg_cap;
@@ -1750,7 +1750,7 @@ int tamp_amd_compress_plan(uint8_t window_bits, uint32_t max_in_len, int lazy_ma
     const uint32_t hb = runlist && window_bits == 10 ? kHb1024 : kHashBits;
     const uint32_t blk = pick_block(W, max_in_len, packed, lazy, runlist, hb);
     const CompressLds L(W, blk, packed, lazy, runlist, hb);
-    const uint32_t reg_cap = lazy ? 5u : (runlist ? (uint32_t)TAMP_WG_PER_CU : 6u);
+    const uint32_t reg_cap = lazy ? (uint32_t)TAMP_LAZY_PER_CU : (runlist ? (uint32_t)TAMP_WG_PER_CU : (uint32_t)TAMP_LEAN_PER_CU);
     const uint32_t by_lds = 160u * 1024u / align_up(L.total, 2048u);
     if (block_positions) *block_positions = blk;
     if (lds_bytes) *lds_bytes = L.total;

@@ -774,6 +774,12 @@ struct Walk {
 #ifndef TAMP_WG_PER_CU
 #define TAMP_WG_PER_CU 8
 #endif
+#ifndef TAMP_LEAN_PER_CU  // (workgroups of 256 threads per CU the lean / lazy builds' registers are budgeted for: 6 -> 80 VGPRs, 5 -> 96)
+#define TAMP_LEAN_PER_CU 6
+#endif
+#ifndef TAMP_LAZY_PER_CU
+#define TAMP_LAZY_PER_CU 5
+#endif
 // Block size after a break (a token that wrote fewer bytes than it consumed threw the rest of the block away): with the
 // 1,536-position blocks of rounds 1-3 halving it (512 at least) was worth 15 % on real text; with 1,024-position blocks
 // at seven workgroups per CU the full block is the better guess again (prose 11.55 -> 10.9 ms, Python sources 28.3 -> 26.8,
@@ -862,7 +868,7 @@ __device__ __forceinline__ T* as_global(T* p) {
 // The work counter hands out blocks instead of streams.  Reference shape: ONE stream of 100 MB (README.md:309-312,
 // tools/c-profiler/main.c:52-54), which one workgroup takes 6 s for.
 template <bool PACKED, bool LAZY, bool RUNS = false, uint32_t WSCAN = 0, uint32_t HB = kHashBits, bool LOOP = false, bool BLOCKM = false>
-__global__ void __launch_bounds__(256, LAZY ? 5 : (RUNS ? TAMP_WG_PER_CU : 6)) tamp_compress_kernel(CompressArgs a_k) {
+__global__ void __launch_bounds__(256, LAZY ? TAMP_LAZY_PER_CU : (RUNS ? TAMP_WG_PER_CU : TAMP_LEAN_PER_CU)) tamp_compress_kernel(CompressArgs a_k) {
     static_assert(!BLOCKM || (LOOP && PACKED && !LAZY), "block mode: a persistent build of the default parse");
     // HB: bucket bits of the bigram index (2,048 buckets; 512 for the short-message build, whose blocks hold a few hundred
     // positions and pay for every cursor zeroed and scanned); the cursor region keeps its size, the walk needs it
