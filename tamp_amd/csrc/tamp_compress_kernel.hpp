@@ -109,7 +109,14 @@ struct CompressLds {
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
         cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
-        o += (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;  // (512-bucket builds keep the full region: the walk needs it)
+        {
+            // (512-bucket builds keep the full region: the walk needs it.  The region also serves as the sorted query list --
+            // blk x u16 -- and, in the run-aware builds, as the walk's explicit pieces + the step table: kSlowCap x 8 + blk bytes)
+            uint32_t cb = (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;
+            if (cb < blk * 2) cb = blk * 2;
+            if (runlist && cb < kSlowCap * 8 + blk) cb = kSlowCap * 8 + blk;
+            o += align_up(cb, 16);
+        }
         tokcap = blk + kPendMax + kRing + 80;
         // lazy matching walks (position, state) pairs: two table slots per position and the transitions themselves
         const uint32_t vblk = lazy ? 2 * blk : blk;
@@ -985,6 +992,17 @@ __global__ void __launch_bounds__(256, LAZY ? TAMP_LAZY_PER_CU : (RUNS ? TAMP_WG
         const bool ext = a.extended != 0;
         const uint32_t maxp = ext ? minp + 11 + kExtExtraMax : minp + 13;  // compressor.c:12-19
         const uint32_t wbits = a_wbits, lbits = a.lbits;
+#ifdef TAMP_POISON_LDS
+        // test builds: every stream starts on LDS full of a pattern that changes from launch to launch and stream to stream, so
+        // that a result which depends on what an earlier workgroup left behind shows in the differential runs at once
+        {
+            __syncthreads();
+            const uint32_t seed = (uint32_t)__builtin_readcyclecounter() | 1u;
+            for (uint32_t k = 4 + tid_k; k < L.total / 4; k += nt)  // (the first four words: this workgroup's claim)
+                reinterpret_cast<uint32_t*>(smem)[k] = (TAMP_POISON_LDS) ? (k + 1) * 2654435761u * seed : 0xFFFFFFFFu;
+            __syncthreads();
+        }
+#endif
         if (tid_k < 15) codetab[tid_k] = (uint8_t)tok_code(tid_k);  // visible after the first barrier (every stream writes the same)
         if (RUNS && tid_k == 0) ctl[cQuad] = 0;  // (first read after the first barrier; every stream leaves it at zero)
 

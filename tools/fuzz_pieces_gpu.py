@@ -62,7 +62,29 @@ while time.time() - t0 < budget:
         else: got_counts.append(c.close())
         calls += 1
     if f.getvalue() != want:
-        print("STREAM MISMATCH", scripts, window, ext, dreset, [(o[0], len(o[1]) if o[0] == 'write' else o[1:]) for o in ops][:40]); sys.exit(1)
+        got = f.getvalue()
+        first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), min(len(got), len(want)))
+        print("STREAM MISMATCH", scripts, window, ext, dreset, "sizes", len(got), len(want), "first differing byte", first,
+              "bytes out before each op", list(np.cumsum(got_counts))[:60],
+              [(o[0], len(o[1]) if o[0] == 'write' else o[1:]) for o in ops][:60], flush=True)
+        again = 0  # the same script three more times: a wrong answer that comes back is an algorithm bug, one that does not is a race
+        for _ in range(3):
+            f2 = io.BytesIO()
+            c2 = tamp_amd.Compressor(f2, window=window, literal=literal, extended=ext, dictionary_reset=dreset)
+            for op in ops:
+                if op[0] == "write": c2.write(op[1])
+                elif op[0] == "flush": c2.flush(op[1])
+                elif op[0] == "reset": c2.reset_dictionary()
+                else: c2.close()
+            again += f2.getvalue() != want
+        print("  replayed 3 times:", again, "wrong", flush=True)
+        try:
+            import pickle
+            os.makedirs("gpurun_out", exist_ok=True)
+            pickle.dump(dict(ops=ops, window=window, ext=ext, dreset=dreset, got=got, want=want), open("gpurun_out/pieces_fail.pkl", "wb"))
+        except Exception as e:  # noqa: BLE001
+            print("  (not saved:", e, ")")
+        sys.exit(1)
     gc, wc = np.cumsum(got_counts), np.cumsum(want_counts)
     for i, op in enumerate(ops):
         d = int(gc[i] - wc[i])
