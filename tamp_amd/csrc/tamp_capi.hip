@@ -249,6 +249,13 @@ uint32_t pick_block(uint32_t W, uint32_t max_in_len, bool packed, bool lazy, boo
     }
     if (const char* e = getenv("TAMP_AMD_BLK")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 64 && v <= 2048) blk = align_up(v, 64); }
     if (blk < 64) blk = 64;
+    {
+        // The cursor region of LDS also serves as the sorted query list (blk x u16) and, in the run-aware builds, as the walk's
+        // explicit pieces + the step table (kSlowCap x 8 + blk bytes): a tuning override must not outgrow it.  (Checked here and
+        // not by sizing the region from the block: that arithmetic inside the kernel cost the 64-VGPR builds their last register.)
+        const uint32_t cur = (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;
+        while (blk > 64 && (blk * 2 > cur || (runlist && kSlowCap * 8 + blk > cur))) blk -= 64;
+    }
     while (W + blk + 16 > 65536) blk >>= 1;  // 16-bit buffer positions
     return blk;
 }

@@ -109,14 +109,7 @@ struct CompressLds {
         ebuf = o;
         o += align_up(W + blk + kRing + kPendMax + 32, 16);
         cnt = o;  // 2048 x u16 bucket cursors; the walk reuses it for explicit token pieces (256 x 8 B)
-        {
-            // (512-bucket builds keep the full region: the walk needs it.  The region also serves as the sorted query list --
-            // blk x u16 -- and, in the run-aware builds, as the walk's explicit pieces + the step table: kSlowCap x 8 + blk bytes)
-            uint32_t cb = (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;
-            if (cb < blk * 2) cb = blk * 2;
-            if (runlist && cb < kSlowCap * 8 + blk) cb = kSlowCap * 8 + blk;
-            o += align_up(cb, 16);
-        }
+        o += (hb < kHashBits ? (1u << hb) : kHashBuckets) * 2;  // (512-bucket builds keep the full region: the walk needs it)
         tokcap = blk + kPendMax + kRing + 80;
         // lazy matching walks (position, state) pairs: two table slots per position and the transitions themselves
         const uint32_t vblk = lazy ? 2 * blk : blk;
