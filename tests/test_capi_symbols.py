@@ -68,6 +68,13 @@ def test_host_helpers_need_no_device(oracle):
         bl, ll, tl, cl = plan(w, 4096, 1)
         assert cl <= 5 and ll <= 160 * 1024
     assert lib.tamp_amd_compress_plan(7, 4096, 0, None, None, None, None) != 0
+    # a tuning override of the block size cannot outgrow the cursor region, which doubles as the sorted query list and the walk's
+    # piece / step tables (1,024 buckets at window 2^10: 2 KB -> 1,024 positions at most; 2,048 buckets elsewhere: 2,048)
+    os.environ["TAMP_AMD_BLK"] = "2048"
+    try:
+        assert plan(10, 4096)[0] == 1024 and plan(9, 4096)[0] == 2048
+    finally:
+        del os.environ["TAMP_AMD_BLK"]
     conf = _lib.TampAmdConf()
     consumed = ctypes.c_size_t(0)
     hdr = (ctypes.c_ubyte * 2)(0x5A, 0)
